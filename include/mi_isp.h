@@ -1,0 +1,151 @@
+/*
+ * mi_isp.h -- C ABI of libmi355_isp.so: the MI355X (gfx950) camera-ISP hot path.
+ *
+ * This is the drop-in boundary.  The reference (uc-vision/taichi_image) exposes this path as
+ * Python functions that launch Taichi-JIT kernels on torch/numpy buffers; there is no FFI in
+ * the reference, so each entry point below cites the reference Python function / Taichi
+ * kernel it replaces (paths relative to /root/reference/taichi_image/).  A maintainer of the
+ * reference would bind these with ctypes exactly as taichi_image_amd/_native.py does
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - every pointer named *_dev is a device (HBM) pointer owned by the caller; the library never
+ *    allocates or frees user-visible memory and never synchronises the stream;
+ *  - images are C-contiguous, [row][col] or [row][col][3] interleaved RGB;
+ *  - `stream` is a hipStream_t (NULL = the default stream); all work is stream-ordered;
+ *  - every function returns 0 on success, non-zero on failure; the message for the calling
+ *    thread is available from mi_isp_last_error();
+ *  - `ws_dev` is a scratch buffer of at least mi_isp_workspace_bytes(H, W) bytes, private to
+ *    one in-flight call (use one per stream / per frame in flight).
+ */
+#ifndef MI_ISP_H
+#define MI_ISP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types (types.py:12-18 scale factors: u8 255, u16 65535, f16 1, f32 1) */
+enum { MI_U8 = 0, MI_U16 = 1, MI_F16 = 2, MI_F32 = 3 };
+/* bayer.py:75-79 BayerPattern values */
+enum { MI_RGGB = 0, MI_GRBG = 1, MI_GBRG = 2, MI_BGGR = 3 };
+/* interpolate.py:9-17 ImageTransform, in declaration order */
+enum {
+  MI_T_NONE = 0, MI_T_ROTATE_90 = 1, MI_T_ROTATE_180 = 2, MI_T_ROTATE_270 = 3,
+  MI_T_TRANSPOSE = 4, MI_T_FLIP_HORIZ = 5, MI_T_FLIP_VERT = 6, MI_T_TRANSVERSE = 7
+};
+/* camera_isp.py:82-99 loaders */
+enum { MI_LOAD_16U = 0, MI_LOAD_32F = 1, MI_LOAD_16F = 2 };
+
+int mi_isp_version(void);
+const char* mi_isp_last_error(void);
+
+/* The 4x13x3 integer demosaic weight tables compiled into the kernels (bayer.py:30-55,
+ * tap order of bayer.py:15-27).  Host-only; used by the tests to pin the tables. */
+int mi_isp_bayer_weights(int32_t out[4 * 13 * 3]);
+
+/* Scratch bytes needed by the calls that take ws_dev, for an H x W frame. */
+size_t mi_isp_workspace_bytes(int H, int W);
+
+/* ---- packed.py ------------------------------------------------------------------------ */
+/* decode12_kernel (packed.py:92-131): 3 bytes -> two 12-bit values; n_px must be even.
+ * scaled: out = cast(f32(v) * f32(scale(out)/4095)).  ids_format: packed.py:37-44 layout. */
+int mi_isp_decode12(const uint8_t* enc_dev, void* out_dev, int64_t n_px, int out_dtype,
+                    int scaled, int ids_format, void* stream);
+/* decode16_kernel (packed.py:135-172): little-endian byte pairs. */
+int mi_isp_decode16(const uint8_t* enc_dev, void* out_dev, int64_t n_px, int out_dtype,
+                    int scaled, void* stream);
+/* encode12_kernel (packed.py:60-89); scaled: v = round_half_away(f32(x) * f32(4095/scale(in))). */
+int mi_isp_encode12(const void* values_dev, uint8_t* enc_dev, int64_t n_px, int in_dtype,
+                    int scaled, int ids_format, void* stream);
+
+/* ---- camera_isp.py loaders (camera_isp.py:82-99) ---------------------------------------- */
+int mi_isp_load_convert(const void* src_dev, void* dst_dev, int64_t n, int mode, int out_dtype,
+                        void* stream);
+
+/* ---- bayer.py ------------------------------------------------------------------------- */
+/* bayer_to_rgb_kernel (bayer.py:115-190): 13-tap diamond demosaic with border
+ * renormalisation; ccm9_host = row-major 3x3 or NULL (host pointer, passed by value). */
+int mi_isp_demosaic(const void* cfa_dev, void* rgb_dev, int H, int W, int in_dtype, int out_dtype,
+                    int pattern, const float* ccm9_host, void* stream);
+/* rgb_to_bayer_kernel (bayer.py:101-112). */
+int mi_isp_mosaic(const void* rgb_dev, void* cfa_dev, int H, int W, int dtype, int pattern,
+                  void* stream);
+
+/* ---- interpolate.py -------------------------------------------------------------------- */
+/* bilinear_kernel (interpolate.py:19-34,59-86): dst (Hd,Wd,3) <- src (Hs,Ws,3);
+ * p = (r/scale0, c/scale1), clamp-to-edge taps, out * scale(out)/scale(in). */
+int mi_isp_resize_bilinear(const void* src_dev, void* dst_dev, int Hs, int Ws, int Hd, int Wd,
+                           float scale0, float scale1, int in_dtype, int out_dtype, void* stream);
+/* transform_kernel (interpolate.py:36-54,93-125); dst is (Ws,Hs,3) for rot90/rot270/transpose. */
+int mi_isp_transform(const void* src_dev, void* dst_dev, int Hs, int Ws, int dtype, int transform,
+                     void* stream);
+
+/* ---- camera_isp.py: rolling metering + tonemap (stateful ISP semantics) ----------------- */
+/* metering_kernel + metering_images (camera_isp.py:142-175): stride-subsampled statistics of
+ * n_images (H,W,3) images, blended into state9_dev (f32[9]) with weight alpha.
+ * images_host: host array of n_images device pointers. */
+int mi_isp_metering(const void* const* images_host, int n_images, int H, int W, int stride,
+                    int dtype, float* state9_dev, float alpha, void* ws_dev, void* stream);
+/* The two data passes of the same kernel, split so that a cross-GPU reduction can be
+ * inserted between them (one process per GPU, see taichi_image_amd/distributed.py):
+ *  bounds: raw (min, max) of the subsample                          -> out2_dev  (f32[2])
+ *  sums  : given blended bounds, [log_min, log_max, sum_log, sum_gray, sum_r, sum_g, sum_b, n]
+ *                                                                    -> out8_dev  (f32[8]) */
+int mi_isp_metering_bounds(const void* const* images_host, int n_images, int H, int W, int stride,
+                           int dtype, float* out2_dev, void* ws_dev, void* stream);
+int mi_isp_metering_sums(const void* const* images_host, int n_images, int H, int W, int stride,
+                         int dtype, const float* bounds2_dev, float* out8_dev, void* ws_dev,
+                         void* stream);
+/* reinhard_kernel (camera_isp.py:177-218): pass 1 writes p back into image_dev IN PLACE (as the
+ * reference does) and reduces max(p); pass 2 writes u8.  transform != NONE applies
+ * interpolate.transform (camera_isp.py:403) while storing; out_dev is then the transformed shape. */
+int mi_isp_reinhard(void* image_dev, uint8_t* out_dev, int H, int W, int dtype,
+                    const float* state9_dev, float gamma, float intensity, float light_adapt,
+                    float color_adapt, int transform, void* ws_dev, void* stream);
+/* linear_kernel (camera_isp.py:220-227 -> tonemap.py:12-17). */
+int mi_isp_linear(const void* image_dev, uint8_t* out_dev, int H, int W, int dtype,
+                  const float* state9_dev, float gamma, int transform, void* ws_dev, void* stream);
+
+/* ---- tonemap.py (stateless, per-image statistics) --------------------------------------- */
+/* linear_kernel (tonemap.py:27-46). */
+int mi_isp_tonemap_linear(const void* src_dev, void* dst_dev, int H, int W, int in_dtype,
+                          int out_dtype, float gamma, void* ws_dev, void* stream);
+/* reinhard_kernel (tonemap.py:135-168): bounds -> normalise -> metering -> Reinhard -> bounds ->
+ * gamma; the f32 `temp` image of the reference is recomputed per pass, never materialised. */
+int mi_isp_tonemap_reinhard(const void* src_dev, void* dst_dev, int H, int W, int in_dtype,
+                            int out_dtype, float gamma, float intensity, float light_adapt,
+                            float color_adapt, void* ws_dev, void* stream);
+
+/* ---- fused hot path ---------------------------------------------------------------------- */
+/* ISP.load_packed12 / load_packed16 (camera_isp.py:333-347,371-373,302-315) in one pass over
+ * the packed frame: unpack (bits = 12|16) -> demosaic (+ccm) -> [bilinear resize] -> rgb_dev
+ * (Hd,Wd,3) of work_dtype (MI_F16 = Camera16, MI_F32 = Camera32).  scale <= 0: no resize
+ * (Hd,Wd must equal H,W).  The intermediate CFA / full-resolution RGB are rounded to
+ * work_dtype exactly where the reference stores them. */
+int mi_isp_load_packed(const uint8_t* packed_dev, void* rgb_dev, int H, int W, int bits,
+                       int ids_format, int pattern, const float* ccm9_host, int work_dtype,
+                       int Hd, int Wd, float scale, void* stream);
+/* The stateless chain of test/pipeline.py:26-32 (BASELINE config 2) fused:
+ * decode12(scaled, work_dtype) -> bayer_to_rgb -> tonemap_reinhard(dtype=out_dtype), four
+ * passes over the packed frame, the only HBM traffic being packed-in and RGB-out. */
+int mi_isp_pipeline12_reinhard(const uint8_t* packed_dev, void* out_dev, int H, int W,
+                               int ids_format, int pattern, const float* ccm9_host,
+                               int work_dtype, int out_dtype, float gamma, float intensity,
+                               float light_adapt, float color_adapt, void* ws_dev, void* stream);
+/* The same for n_frames independent frames, frame i on streams_host[i % n_streams]
+ * (one frame per stream in flight); ws_dev holds n_frames consecutive workspaces. */
+int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed_host, void* const* out_host,
+                                     int n_frames, int H, int W, int ids_format, int pattern,
+                                     const float* ccm9_host, int work_dtype, int out_dtype,
+                                     float gamma, float intensity, float light_adapt,
+                                     float color_adapt, void* ws_dev, void* const* streams_host,
+                                     int n_streams);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ISP_H */

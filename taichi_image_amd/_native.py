@@ -1,0 +1,119 @@
+"""ctypes binding of libmi355_isp.so (include/mi_isp.h) and device-buffer plumbing.
+
+PyTorch-ROCm tensors are only the device-buffer / stream provider here.  There is no CPU
+fallback: every public op raises if the HIP library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355_isp.so")
+
+MI_U8, MI_U16, MI_F16, MI_F32 = 0, 1, 2, 3
+
+# every symbol include/mi_isp.h declares: name -> (restype, argtypes)
+_P = c_void_p
+SIGNATURES = {
+    "mi_isp_version": (c_int, []),
+    "mi_isp_last_error": (c_char_p, []),
+    "mi_isp_bayer_weights": (c_int, [POINTER(c_int32)]),
+    "mi_isp_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mi_isp_decode12": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P]),
+    "mi_isp_decode16": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "mi_isp_encode12": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P]),
+    "mi_isp_load_convert": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "mi_isp_demosaic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P]),
+    "mi_isp_mosaic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mi_isp_resize_bilinear": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P]),
+    "mi_isp_transform": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mi_isp_metering": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P]),
+    "mi_isp_metering_bounds": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "mi_isp_metering_sums": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "mi_isp_reinhard": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_float, c_float, c_float, c_float, c_int, _P, _P]),
+    "mi_isp_linear": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_float, c_int, _P, _P]),
+    "mi_isp_tonemap_linear": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    "mi_isp_tonemap_reinhard": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, _P, _P]),
+    "mi_isp_load_packed": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_int,
+                                   c_float, _P]),
+    "mi_isp_pipeline12_reinhard": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int,
+                                           c_float, c_float, c_float, c_float, _P, _P]),
+    "mi_isp_pipeline12_reinhard_batch": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, c_int,
+                                                 POINTER(c_float), c_int, c_int, c_float, c_float, c_float, c_float,
+                                                 _P, POINTER(_P), c_int]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library (once).  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise NativeLibraryError(
+                        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C taichi_image_amd/csrc`).  There is no CPU fallback.")
+                L = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol
+                    fn.restype, fn.argtypes = res, args
+                _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("libmi355_isp: " + lib().mi_isp_last_error().decode("utf-8", "replace"))
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise RuntimeError("taichi_image_amd needs an MI355X (HIP) device; there is no CPU fallback")
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ccm_arg(correct_colors):
+    """3x3 colour matrix (row-major) -> float[9] or NULL (bayer.py:210-211)."""
+    if correct_colors is None:
+        return None
+    m = np.asarray(correct_colors, dtype=np.float64).reshape(-1)
+    assert m.size == 9, "colour correction must be a 3x3 matrix"
+    return (c_float * 9)(*[float(v) for v in m])
+
+
+_ws_cache: dict = {}
+
+
+def workspace(H: int, W: int, device: torch.device, slots: int = 1) -> torch.Tensor:
+    """Scratch buffer for one in-flight call on (device, current stream)."""
+    nbytes = int(lib().mi_isp_workspace_bytes(int(H), int(W))) * slots
+    key = (device.index or 0, stream_ptr(device), nbytes)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        if len(_ws_cache) > 64:
+            _ws_cache.clear()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def ptr_array(tensors):
+    arr = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr

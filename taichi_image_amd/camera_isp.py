@@ -1,0 +1,306 @@
+"""Stateful camera ISP -- call surface of taichi_image/camera_isp.py (Camera16 / Camera32).
+
+load (unpack/normalise) -> demosaic(+colour matrix) -> resize; rolling metering statistics;
+Reinhard / linear tonemap to u8; orientation transform.  All device work is HIP
+(csrc/): the load path is one fused tile kernel over the packed frame, the tonemaps are
+two-pass elementwise kernels with wave-shuffle reductions.
+
+Deliberate differences from the reference (see DESIGN.md "quirks"):
+ * `_process_image` forwards `self.bayer_pattern` (the reference drops it and always demosaics
+   RGGB, camera_isp.py:372); identical for RGGB.
+ * tonemap parameters are runtime floats (the reference re-JITs per value).
+ * NaN / out-of-range float->u8 casts are defined (0 / saturate) where the reference is undefined.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _native, bayer, interpolate, packed, types
+from . import distributed as _dist
+
+default_cc = np.array([      # camera_isp.py:230-234
+    [1.75, -0.25, -0.30],
+    [-0.10, 1.40, -0.30],
+    [-0.05, -0.55, 2.10],
+])
+
+
+def _typecheck(name, value, kinds, optional=False):
+    if optional and value is None:
+        return
+    if isinstance(value, bool) and bool not in (kinds if isinstance(kinds, tuple) else (kinds,)):
+        raise TypeError(f"{name} must be {kinds}, got bool")
+    if not isinstance(value, kinds):
+        raise TypeError(f"{name} must be {kinds}, got {type(value).__name__}")
+
+
+def camera_isp(name: str, dtype=types.f32):
+    """camera_isp.py:75-418: class factory specialised on the working dtype."""
+    dtype = types.as_dtype(dtype)
+    torch_dtype = types.ti_to_torch[dtype]
+
+    def _check_image(image, what="image"):
+        if not isinstance(image, torch.Tensor):
+            raise TypeError(f"{what} must be a torch.Tensor")
+        assert image.ndim == 3 and image.shape[2] == 3, f"{what} must be (H, W, 3)"
+        assert image.dtype == torch_dtype, f"{what} must be {torch_dtype}, got {image.dtype}"
+        assert image.is_cuda and image.is_contiguous(), f"{what} must be a contiguous device tensor"
+
+    def reinhard_kernel(image, output, metering, gamma, intensity, light_adapt, color_adapt,
+                        transform=interpolate.ImageTransform.none):
+        """camera_isp.py:177-218.  Mutates `image` (p written back in place), fills `output`."""
+        _check_image(image)
+        H, W = image.shape[:2]
+        ws = _native.workspace(H, W, image.device)
+        _native.check(_native.lib().mi_isp_reinhard(
+            image.data_ptr(), output.data_ptr(), H, W, dtype.code, metering.data_ptr(), float(gamma),
+            float(intensity), float(light_adapt), float(color_adapt), interpolate.transform_code(transform),
+            ws.data_ptr(), _native.stream_ptr(image.device)))
+
+    def linear_kernel(image, output, metering, gamma, transform=interpolate.ImageTransform.none):
+        """camera_isp.py:220-227."""
+        _check_image(image)
+        H, W = image.shape[:2]
+        ws = _native.workspace(H, W, image.device)
+        _native.check(_native.lib().mi_isp_linear(
+            image.data_ptr(), output.data_ptr(), H, W, dtype.code, metering.data_ptr(), float(gamma),
+            interpolate.transform_code(transform), ws.data_ptr(), _native.stream_ptr(image.device)))
+
+    def _out_shape(image, transform):
+        H, W = image.shape[:2]
+        if transform in (interpolate.ImageTransform.rotate_90, interpolate.ImageTransform.rotate_270,
+                         interpolate.ImageTransform.transpose):
+            return (W, H, 3)
+        return (H, W, 3)
+
+    class ISP():
+        def __init__(self, bayer_pattern: bayer.BayerPattern,
+                     scale: Optional[float] = None,
+                     resize_width: int = 0,
+                     moving_alpha=0.1,
+                     correct_colors: bool = False,
+                     white_balance: np.ndarray = np.array([1.8, 1.0, 2.1]),
+                     color_correction: np.ndarray = default_cc,
+                     transform: interpolate.ImageTransform = interpolate.ImageTransform.none,
+                     device: torch.device = torch.device('cuda', 0),
+                     metering_stride: int = 8,
+                     process_group=None):
+            _typecheck("bayer_pattern", bayer_pattern, bayer.BayerPattern)
+            _typecheck("scale", scale, float, optional=True)
+            _typecheck("resize_width", resize_width, int)
+            _typecheck("correct_colors", correct_colors, bool)
+            _typecheck("white_balance", white_balance, np.ndarray)
+            _typecheck("color_correction", color_correction, np.ndarray)
+            _typecheck("transform", transform, interpolate.ImageTransform)
+            _typecheck("device", device, torch.device)
+            _typecheck("metering_stride", metering_stride, int)
+            assert scale is None or resize_width == 0, "Cannot specify both scale and resize_width"
+
+            self.bayer_pattern = bayer_pattern
+            self.moving_alpha = moving_alpha
+            self.scale = scale
+            self.resize_width = resize_width
+            self.transform = transform
+            self.metering_stride = metering_stride
+
+            self.correct_colors = correct_colors
+            self.white_balance = white_balance
+            self.color_correction = color_correction
+
+            self.metrics = None
+            self.device = device
+            # one-process-per-GPU sharding: statistics are all-reduced over this group (RCCL)
+            self.process_group = process_group
+
+        def set(self, moving_alpha: Optional[float] = None, resize_width: Optional[int] = None,
+                scale: Optional[float] = None,
+                correct_colors: Optional[bool] = None,
+                white_balance: Optional[np.ndarray] = None,
+                color_correction: Optional[np.ndarray] = None,
+                transform: Optional[interpolate.ImageTransform] = None):
+            """camera_isp.py:270-300."""
+            _typecheck("moving_alpha", moving_alpha, float, optional=True)
+            _typecheck("resize_width", resize_width, int, optional=True)
+            _typecheck("scale", scale, float, optional=True)
+            _typecheck("correct_colors", correct_colors, bool, optional=True)
+            _typecheck("white_balance", white_balance, np.ndarray, optional=True)
+            _typecheck("color_correction", color_correction, np.ndarray, optional=True)
+            _typecheck("transform", transform, interpolate.ImageTransform, optional=True)
+            if moving_alpha is not None:
+                self.moving_alpha = moving_alpha
+            if resize_width is not None:
+                self.resize_width = resize_width
+                self.scale = None
+            if scale is not None:
+                self.scale = scale
+                self.resize_width = 0
+            if transform is not None:
+                self.transform = transform
+            if correct_colors is not None:
+                self.correct_colors = correct_colors
+            if white_balance is not None:
+                self.white_balance = white_balance
+            if color_correction is not None:
+                self.color_correction = color_correction
+
+        def resize_image(self, image):
+            """camera_isp.py:302-315."""
+            w, h = image.shape[1], image.shape[0]
+            if self.resize_width > 0:
+                scale = self.resize_width / w
+                output_size = (self.resize_width, round(h * scale))
+                return interpolate.resize_bilinear(image, output_size, scale)
+            elif self.scale is not None:
+                output_size = (round(w * self.scale), round(h * self.scale))
+                return interpolate.resize_bilinear(image, output_size, self.scale)
+            else:
+                return image
+
+        def _convert(self, image, mode, src_dtype):
+            if not isinstance(image, torch.Tensor):
+                raise TypeError("image must be a torch.Tensor")
+            assert image.ndim == 2, "image must be a 2-D CFA"
+            assert image.dtype == src_dtype, f"image must be {src_dtype}, got {image.dtype}"
+            src = image.to(self.device).contiguous()
+            cfa = torch.empty(image.shape, dtype=torch_dtype, device=self.device)
+            _native.check(_native.lib().mi_isp_load_convert(src.data_ptr(), cfa.data_ptr(), cfa.numel(), mode,
+                                                            dtype.code, _native.stream_ptr(self.device)))
+            return self._process_image(cfa)
+
+        def load_16u(self, image):
+            """camera_isp.py:318-321 (kernel :82-87)."""
+            return self._convert(image, 0, torch.uint16)
+
+        def load_16f(self, image):
+            """camera_isp.py:323-326 (kernel :95-99: u16 converted numerically)."""
+            return self._convert(image, 2, torch.uint16)
+
+        def load_32f(self, image):
+            """camera_isp.py:328-331 (kernel :89-93)."""
+            return self._convert(image, 1, torch.float32)
+
+        def _load_packed(self, image_data, bits, ids_format):
+            if not isinstance(image_data, torch.Tensor):
+                raise TypeError("image_data must be a torch.Tensor")
+            assert image_data.ndim == 2 and image_data.dtype == torch.uint8, "image_data must be (H, bytes) uint8"
+            if bits == 12:
+                assert image_data.shape[1] % 3 == 0, "packed-12 rows must hold whole pixel pairs (bytes % 3 == 0)"
+                w, h = (image_data.shape[1] * 2 // 3, image_data.shape[0])        # camera_isp.py:336
+            else:
+                w, h = (image_data.shape[1] // 2, image_data.shape[0])             # camera_isp.py:343
+            assert w % 2 == 0 and h % 2 == 0, "image must be even size"
+            src = image_data.to(self.device).contiguous()
+            rgb = torch.empty((h, w, 3), dtype=torch_dtype, device=self.device)
+            _native.check(_native.lib().mi_isp_load_packed(
+                src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
+                _native.ccm_arg(self.color_correct_matrix), dtype.code, h, w, 0.0,
+                _native.stream_ptr(self.device)))
+            return self.resize_image(rgb)
+
+        def load_packed12(self, image_data, ids_format=False):
+            """camera_isp.py:333-340: unpack + demosaic (+ccm) fused in one pass over the packed frame."""
+            return self._load_packed(image_data, 12, ids_format)
+
+        def load_packed16(self, image_data):
+            """camera_isp.py:342-347."""
+            return self._load_packed(image_data, 16, False)
+
+        @property
+        def color_correct_matrix(self) -> Optional[np.ndarray]:
+            """camera_isp.py:360-369: cc with column j scaled by white_balance[j]."""
+            if self.correct_colors:
+                cc = self.color_correction.copy()
+                cc[:, :3] *= self.white_balance
+                return cc
+            return None
+
+        def _process_image(self, cfa):
+            """camera_isp.py:371-373."""
+            rgb = bayer.bayer_to_rgb(cfa, pattern=self.bayer_pattern, correct_colors=self.color_correct_matrix)
+            return self.resize_image(rgb)
+
+        def _metering_images(self, images, t, prev):
+            """camera_isp.py:168-175: statistics of the stride-subsampled images, blended into a
+            copy of `prev`; the subsample is gathered in-kernel (no torch.stack copy)."""
+            assert len(images) > 0, "need at least one image"
+            for im in images:
+                _check_image(im)
+                assert im.shape == images[0].shape, "all images of one call must share a shape"
+            H, W = images[0].shape[:2]
+            ws = _native.workspace(H, W, self.device)
+            ptrs = _native.ptr_array(images)
+            L = _native.lib()
+            stream = _native.stream_ptr(self.device)
+            if self.process_group is None:
+                metering = prev.clone()
+                _native.check(L.mi_isp_metering(ptrs, len(images), H, W, self.metering_stride, dtype.code,
+                                                metering.data_ptr(), float(t), ws.data_ptr(), stream))
+                return metering
+            # sharded batch: same arithmetic with two tiny RCCL exchanges between the data passes
+            raw = torch.empty(2, dtype=torch.float32, device=self.device)
+            _native.check(L.mi_isp_metering_bounds(ptrs, len(images), H, W, self.metering_stride, dtype.code,
+                                                   raw.data_ptr(), ws.data_ptr(), stream))
+            raw = _dist.allreduce_bounds(raw, self.process_group)
+            b = _dist.blend_bounds(raw, prev, t)
+            part = torch.empty(8, dtype=torch.float32, device=self.device)
+            _native.check(L.mi_isp_metering_sums(ptrs, len(images), H, W, self.metering_stride, dtype.code,
+                                                 b.data_ptr(), part.data_ptr(), ws.data_ptr(), stream))
+            part = _dist.allreduce_sums(part, self.process_group)
+            return _dist.finish_metering(prev, b, part, t)
+
+        def update_metering(self, images: List[torch.Tensor]):
+            """camera_isp.py:376-385."""
+            if self.metrics is None:
+                initial = torch.zeros(9, dtype=torch.float32, device=self.device)
+                self.metrics = self._metering_images(images, 0.0, initial)
+            else:
+                self.metrics = self._metering_images(images, (1.0 - self.moving_alpha), self.metrics)
+
+        def tonemap_only(self, image, metrics, gamma, intensity, light_adapt, color_adapt):
+            """camera_isp.py:387-390."""
+            output = torch.empty(_out_shape(image, self.transform), dtype=torch.uint8, device=self.device)
+            reinhard_kernel(image, output, metrics, gamma, intensity, light_adapt, color_adapt, self.transform)
+            return output
+
+        def tonemap_reinhard(self, images: List[torch.Tensor],
+                             gamma: float = 1.0, intensity: float = 1.0, light_adapt: float = 1.0,
+                             color_adapt: float = 0.0):
+            """camera_isp.py:394-403.  NOTE: like the reference, pass 1 overwrites each input image
+            with the Reinhard-mapped values (camera_isp.py:211)."""
+            _typecheck("images", images, list)
+            for n, v in (("gamma", gamma), ("intensity", intensity), ("light_adapt", light_adapt),
+                         ("color_adapt", color_adapt)):
+                _typecheck(n, v, float)
+            self.update_metering(images)
+            outputs = [torch.empty(_out_shape(image, self.transform), dtype=torch.uint8, device=self.device)
+                       for image in images]
+            for output, image in zip(outputs, images):
+                # the orientation transform (camera_isp.py:403) is folded into the u8 store
+                reinhard_kernel(image, output, self.metrics, gamma, intensity, light_adapt, color_adapt,
+                                self.transform)
+            return outputs
+
+        def tonemap_linear(self, images: List[torch.Tensor], gamma: float = 1.0):
+            """camera_isp.py:405-413."""
+            _typecheck("images", images, list)
+            _typecheck("gamma", gamma, float)
+            self.update_metering(images)
+            outputs = [torch.empty(_out_shape(image, self.transform), dtype=torch.uint8, device=self.device)
+                       for image in images]
+            for output, image in zip(outputs, images):
+                linear_kernel(image, output, self.metrics, gamma, self.transform)
+            return outputs
+
+    ISP.reinhard_kernel = staticmethod(reinhard_kernel)
+    ISP.linear_kernel = staticmethod(linear_kernel)
+    ISP.dtype = dtype
+    ISP.__name__ = name
+    ISP.__qualname__ = name
+    return ISP
+
+
+Camera16 = camera_isp("Camera16", types.f16)
+Camera32 = camera_isp("Camera32", types.f32)

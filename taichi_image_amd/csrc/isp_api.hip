@@ -1,0 +1,175 @@
+// C ABI of the tile-based entry points (demosaic, fused load, fused config-2 pipeline) plus the
+// library-wide plumbing (version, error string, workspace size).
+#include <stdarg.h>
+
+#include "isp_elementwise.h"
+#include "isp_tile.h"
+
+static thread_local char g_err[512] = "";
+
+void mi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int mi_isp_version(void) { return 1000; }  // 0.1.0 -> major*1e4 + minor*1e3 ... (monotone)
+extern "C" const char* mi_isp_last_error(void) { return g_err; }
+
+extern "C" int mi_isp_bayer_weights(int32_t out[4 * 13 * 3]) {
+  MI_REQUIRE(out, "bayer_weights: null pointer");
+  // host copy of the table the kernels are compiled with (isp_tile.h: tile::KW)
+  static const int8_t kw[4][13][3] = {
+      {{0, -2, -3}, {0, 0, 4}, {0, 4, 0}, {0, 0, 4}, {0, -2, -3}, {0, 4, 0}, {16, 8, 12},
+       {0, 4, 0}, {0, -2, -3}, {0, 0, 4}, {0, 4, 0}, {0, 0, 4}, {0, -2, -3}},
+      {{-2, 0, 1}, {-2, 0, -2}, {8, 0, 0}, {-2, 0, -2}, {1, 0, -2}, {0, 0, 8}, {10, 16, 10},
+       {0, 0, 8}, {1, 0, -2}, {-2, 0, -2}, {8, 0, 0}, {-2, 0, -2}, {-2, 0, 1}},
+      {{1, 0, -2}, {-2, 0, -2}, {0, 0, 8}, {-2, 0, -2}, {-2, 0, 1}, {8, 0, 0}, {10, 16, 10},
+       {8, 0, 0}, {-2, 0, 1}, {-2, 0, -2}, {0, 0, 8}, {-2, 0, -2}, {1, 0, -2}},
+      {{-3, -2, 0}, {4, 0, 0}, {0, 4, 0}, {4, 0, 0}, {-3, -2, 0}, {0, 4, 0}, {12, 8, 16},
+       {0, 4, 0}, {-3, -2, 0}, {4, 0, 0}, {0, 4, 0}, {4, 0, 0}, {-3, -2, 0}}};
+  for (int k = 0; k < 4; ++k)
+    for (int t = 0; t < 13; ++t)
+      for (int c = 0; c < 3; ++c) out[(k * 13 + t) * 3 + c] = kw[k][t][c];
+  return 0;
+}
+
+extern "C" size_t mi_isp_workspace_bytes(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  return (size_t)(FP_COUNT + 8 * (size_t)mi_partial_cap(H, W)) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------
+static int fill_common(tile::Params& p, int H, int W, int pattern, const float* ccm9, const char* who) {
+  MI_REQUIRE(H > 0 && W > 0, "%s: bad shape %dx%d", who, H, W);
+  MI_REQUIRE(H % 2 == 0 && W % 2 == 0, "%s: image must be even size, got %dx%d", who, H, W);  // bayer.py:206
+  MI_REQUIRE(pattern >= MI_RGGB && pattern <= MI_BGGR, "%s: bad pattern %d", who, pattern);
+  p.H = H; p.W = W;
+  p.has_ccm = ccm9 != nullptr;
+  for (int i = 0; i < 9; ++i) p.ccm[i] = ccm9 ? ccm9[i] : (i % 4 == 0 ? 1.f : 0.f);
+  p.gamma_inv = 1.f; p.la = 1.f; p.ca = 0.f;
+  return 0;
+}
+
+static int vec_store_ok(const void* dst, int W, int out_dtype) {
+  // a strip row is 24 contiguous elements at element offset (r*W + c)*3, c % 8 == 0
+  return W % 8 == 0 && mi_aligned(dst, out_dtype == MI_U8 ? 8 : 16);
+}
+
+extern "C" int mi_isp_demosaic(const void* cfa, void* rgb, int H, int W, int in_dtype, int out_dtype, int pattern,
+                               const float* ccm9, void* stream) {
+  MI_REQUIRE(cfa && rgb, "demosaic: null pointer");
+  MI_REQUIRE(mi_valid_dtype(in_dtype) && mi_valid_dtype(out_dtype), "demosaic: bad dtype");
+  tile::Params p = {};
+  if (int rc = fill_common(p, H, W, pattern, ccm9, "demosaic")) return rc;
+  p.src = cfa; p.dst = rgb;
+  p.src_kind = in_dtype;                       // SRC_CFA_* share the MI_* numbering
+  p.out_dtype = out_dtype;
+  p.vec_store = vec_store_ok(rgb, W, out_dtype);
+  p.in_scale = mi_scale_factor(in_dtype);
+  p.out_scale = mi_scale_factor(out_dtype);
+  // work type: f16 holds u8 and f16 inputs exactly; u16 / f32 need f32
+  const int work = (in_dtype == MI_U8 || in_dtype == MI_F16) ? MI_F16 : MI_F32;
+  return tile::launch(p, work, pattern, tile::EPI_STORE, (hipStream_t)stream);
+}
+
+static int packed_params(tile::Params& p, const uint8_t* packed, int H, int W, int bits, int ids_format,
+                         int work_dtype, const char* who) {
+  MI_REQUIRE(packed, "%s: null packed pointer", who);
+  MI_REQUIRE(bits == 12 || bits == 16, "%s: bits must be 12 or 16, got %d", who, bits);
+  MI_REQUIRE(work_dtype == MI_F16 || work_dtype == MI_F32, "%s: work dtype must be f16 or f32", who);
+  p.src = packed;
+  p.src_kind = bits == 16 ? tile::SRC_PACKED16 : (ids_format ? tile::SRC_PACKED12_IDS : tile::SRC_PACKED12);
+  p.src_fast = bits == 16 ? (W % 8 == 0 && mi_aligned(packed, 16)) : (W % 8 == 0 && mi_aligned(packed, 4));
+  p.in_scale = 1.f;                            // the decoded CFA is f16/f32 in [0, 1]
+  p.k_decode = (float)(1.0 / (bits == 16 ? 65535.0 : 4095.0));   // packed.py:99,140 with scale 1.0
+  return 0;
+}
+
+extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,
+                                  int pattern, const float* ccm9, int work_dtype, int Hd, int Wd, float scale,
+                                  void* stream) {
+  MI_REQUIRE(rgb, "load_packed: null output");
+  tile::Params p = {};
+  if (int rc = fill_common(p, H, W, pattern, ccm9, "load_packed")) return rc;
+  if (int rc = packed_params(p, packed, H, W, bits, ids_format, work_dtype, "load_packed")) return rc;
+  MI_REQUIRE(scale <= 0.f, "load_packed: fused resize not available in this build; resize separately");
+  MI_REQUIRE(Hd == H && Wd == W, "load_packed: output shape must equal the frame when scale <= 0");
+  p.dst = rgb; p.out_dtype = work_dtype; p.out_scale = 1.f;
+  p.vec_store = vec_store_ok(rgb, W, work_dtype);
+  return tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream);
+}
+
+// One frame of the fused config-2 chain: four tile passes + three finalize launches.
+static int pipeline_frame(tile::Params p, int pattern, int work_dtype, float intensity, float* ws, hipStream_t s) {
+  float* fp = ws;
+  float* partials = ws + FP_COUNT;
+  const int cap = mi_partial_cap(p.H, p.W);
+  const int nb = tile::num_tiles(p.H, p.W);
+  p.fp = fp; p.partials = partials; p.part_stride = cap;
+  ew::FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
+  fa.n_px = (float)((int64_t)p.H * p.W); fa.intensity = intensity; fa.la = p.la; fa.ca = p.ca;
+  if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_MINMAX, s)) return rc;      // tonemap.py:146
+  if (int rc = ew::finalize(ew::FIN_BOUNDS, fa, s)) return rc;
+  if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STATS, s)) return rc;       // :147-149
+  if (int rc = ew::finalize(ew::FIN_STATS, fa, s)) return rc;
+  if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_RH_MINMAX, s)) return rc;   // :150,153
+  if (int rc = ew::finalize(ew::FIN_BOUNDS2, fa, s)) return rc;
+  return tile::launch(p, work_dtype, pattern, tile::EPI_RH_STORE, s);                      // :154
+}
+
+static int pipeline_params(tile::Params& p, int H, int W, int ids_format, int pattern, const float* ccm9,
+                           int work_dtype, int out_dtype, float gamma, float la, float ca) {
+  if (int rc = fill_common(p, H, W, pattern, ccm9, "pipeline12_reinhard")) return rc;
+  MI_REQUIRE(mi_valid_dtype(out_dtype), "pipeline12_reinhard: bad output dtype");
+  MI_REQUIRE(gamma > 0.f, "pipeline12_reinhard: gamma must be positive");
+  MI_REQUIRE(work_dtype == MI_F16 || work_dtype == MI_F32, "pipeline12_reinhard: work dtype must be f16/f32");
+  (void)ids_format;
+  p.out_dtype = out_dtype;
+  p.out_scale = mi_scale_factor(out_dtype);
+  p.gamma_inv = 1.0f / gamma; p.la = la; p.ca = ca;
+  return 0;
+}
+
+extern "C" int mi_isp_pipeline12_reinhard(const uint8_t* packed, void* out, int H, int W, int ids_format,
+                                          int pattern, const float* ccm9, int work_dtype, int out_dtype,
+                                          float gamma, float intensity, float light_adapt, float color_adapt,
+                                          void* ws, void* stream) {
+  MI_REQUIRE(out && ws, "pipeline12_reinhard: null pointer");
+  tile::Params p = {};
+  if (int rc = pipeline_params(p, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma, light_adapt,
+                               color_adapt))
+    return rc;
+  if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, "pipeline12_reinhard")) return rc;
+  p.dst = out;
+  p.vec_store = vec_store_ok(out, W, out_dtype);
+  return pipeline_frame(p, pattern, work_dtype, intensity, static_cast<float*>(ws), (hipStream_t)stream);
+}
+
+extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, void* const* out, int n_frames, int H,
+                                                int W, int ids_format, int pattern, const float* ccm9,
+                                                int work_dtype, int out_dtype, float gamma, float intensity,
+                                                float light_adapt, float color_adapt, void* ws,
+                                                void* const* streams, int n_streams) {
+  MI_REQUIRE(packed && out && ws, "pipeline12_reinhard_batch: null pointer");
+  MI_REQUIRE(n_frames >= 0, "pipeline12_reinhard_batch: negative frame count");
+  MI_REQUIRE(n_streams >= 1 && streams, "pipeline12_reinhard_batch: need at least one stream");
+  tile::Params base = {};
+  if (int rc = pipeline_params(base, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma, light_adapt,
+                               color_adapt))
+    return rc;
+  const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
+  for (int i = 0; i < n_frames; ++i) {
+    MI_REQUIRE(out[i], "pipeline12_reinhard_batch: output %d is null", i);
+    tile::Params p = base;
+    if (int rc = packed_params(p, packed[i], H, W, 12, ids_format, work_dtype, "pipeline12_reinhard_batch")) return rc;
+    p.dst = out[i];
+    p.vec_store = vec_store_ok(out[i], W, out_dtype);
+    if (int rc = pipeline_frame(p, pattern, work_dtype, intensity, static_cast<float*>(ws) + (size_t)i * ws_floats,
+                                (hipStream_t)streams[i % n_streams]))
+      return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,124 @@
+// Shared host/device helpers for libmi355_isp.so (gfx950 only, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mi_isp.h"
+
+typedef _Float16 half_t;
+
+// ---- host-side error handling ---------------------------------------------------------------
+void mi_set_error(const char* fmt, ...);   // defined in isp_api.hip (thread-local buffer)
+
+#define MI_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      mi_set_error(__VA_ARGS__);         \
+      return 1;                          \
+    }                                    \
+  } while (0)
+
+#define MI_HIP(expr)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      mi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return 2;                                                                   \
+    }                                                                             \
+  } while (0)
+
+#define MI_LAUNCH_CHECK() MI_HIP(hipGetLastError())
+
+static inline bool mi_valid_dtype(int d) { return d >= MI_U8 && d <= MI_F32; }
+static inline size_t mi_dtype_size(int d) { return d == MI_U8 ? 1 : (d == MI_F32 ? 4 : 2); }
+static inline float mi_scale_factor(int d) { return d == MI_U8 ? 255.f : (d == MI_U16 ? 65535.f : 1.f); }
+static inline bool mi_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ---- device helpers ---------------------------------------------------------------------------
+#define MI_DEV __device__ __forceinline__
+
+// ti.cast(f32 -> T): RNE for floats, truncation for unsigned ints.  NaN -> 0 and saturation are
+// the library's definition where the reference is undefined (fptoui poison).
+template <class T> MI_DEV T cast_out(float x);
+template <> MI_DEV float cast_out<float>(float x) { return x; }
+template <> MI_DEV half_t cast_out<half_t>(float x) { return (half_t)x; }
+template <> MI_DEV uint8_t cast_out<uint8_t>(float x) {
+  x = fminf(fmaxf(x, 0.f), 255.f);  // fmaxf(NaN, 0) == 0
+  return (uint8_t)(unsigned)x;
+}
+template <> MI_DEV uint16_t cast_out<uint16_t>(float x) {
+  x = fminf(fmaxf(x, 0.f), 65535.f);
+  return (uint16_t)(unsigned)x;
+}
+
+template <class T> MI_DEV float to_f32(T v) { return (float)v; }
+
+template <class T> struct ScaleOf { static constexpr float value = 1.f; };
+template <> struct ScaleOf<uint8_t> { static constexpr float value = 255.f; };
+template <> struct ScaleOf<uint16_t> { static constexpr float value = 65535.f; };
+
+// NaN-ignoring min/max (v_min_f32 / v_max_f32 semantics, == llvm.minnum/maxnum)
+MI_DEV float nmin(float a, float b) { return fminf(a, b); }
+MI_DEV float nmax(float a, float b) { return fmaxf(a, b); }
+
+MI_DEV float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+MI_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+MI_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block reduction of up to 8 values per thread for 256-thread blocks (4 waves): each wave
+// shuffles down to one value, the per-wave results meet in LDS, thread k < NV combines them
+// and stores partial[k * stride + block].  op[k]: 0 = min, 1 = max, 2 = sum.
+template <int NV>
+MI_DEV void block_reduce_store(const float (&v)[NV], const int (&op)[NV], float (*red)[8],
+                               float* partials, int stride, int block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float r = op[k] == 0 ? wave_min(v[k]) : (op[k] == 1 ? wave_max(v[k]) : wave_sum(v[k]));
+    if (lane == 0) red[wave][k] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int k = threadIdx.x;
+    float r = red[0][k];
+    const int nw = blockDim.x >> 6;
+    for (int w = 1; w < nw; ++w) {
+      float o = red[w][k];
+      r = op[k] == 0 ? fminf(r, o) : (op[k] == 1 ? fmaxf(r, o) : r + o);
+    }
+    partials[(size_t)k * stride + block] = r;
+  }
+}
+
+// ---- per-frame workspace layout (floats) ---------------------------------------------------------
+// [0, 64)            : FrameParams -- scalars produced by the finalize kernels, read by later passes
+// [64, 64 + 8*cap)   : per-block partials, SoA: partial[k][block]
+enum {
+  FP_LO = 0, FP_HI = 1, FP_INV = 2,                 // bounds of the input image, 1/(hi-lo)
+  FP_BMIN = 3, FP_BMAX = 4, FP_LMEAN = 5, FP_GMEAN = 6, FP_RMEAN = 7, /* 8, 9 */
+  FP_MAPKEY = 10, FP_EI = 11, FP_MEAN3 = 12, /* 13, 14 */
+  FP_LO2 = 15, FP_HI2 = 16, FP_INV2 = 17,           // bounds of the Reinhard image
+  FP_MAXOUT = 18,                                   // ISP reinhard: max(1e-6, max p)
+  FP_COUNT = 64
+};
+static inline int mi_partial_cap(int H, int W) {
+  // enough blocks for the tile kernels (128x32 px tiles) and the elementwise reductions
+  long tiles = (long)((W + 127) / 128) * ((H + 31) / 32);
+  long cap = tiles < 4096 ? 4096 : tiles;
+  return (int)cap;
+}

@@ -1,0 +1,992 @@
+// Elementwise / gather kernels of the camera-ISP path and the small finalize kernels that turn
+// per-block partials into the scalars of the next pass.  All of these are HBM- (or launch-)
+// bound byte movers: wide coalesced accesses, no LDS tiling, wave-shuffle reductions.
+#include "isp_elementwise.h"
+#include "isp_math.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+static inline int grid_for(int64_t work_items, int cap = 256 * 16) {
+  int64_t b = (work_items + EW_THREADS - 1) / EW_THREADS;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+template <class F> static int dispatch_dtype(int dtype, F&& f) {
+  switch (dtype) {
+    case MI_U8: return f((uint8_t)0);
+    case MI_U16: return f((uint16_t)0);
+    case MI_F16: return f((half_t)0);
+    default: return f((float)0);
+  }
+}
+
+// unpack helpers shared with the tile kernels ------------------------------------------------
+MI_DEV void unpack_pair(uint32_t w, bool ids, uint32_t& p0, uint32_t& p1) {
+  if (!ids) {
+    p0 = w & 0xFFFu;
+    p1 = (w >> 12) & 0xFFFu;
+  } else {
+    const uint32_t b0 = w & 0xFFu, b1 = (w >> 8) & 0xFFu, b2 = (w >> 16) & 0xFFu;
+    p0 = (b0 << 4) | (b2 & 0xFu);
+    p1 = (b1 << 4) | (b2 >> 4);
+  }
+}
+
+template <class T> MI_DEV T write_value(uint32_t v, bool scaled, float k) {
+  // packed.py:98-104: scaled -> cast(f32(v) * k); direct -> numeric conversion
+  return scaled ? cast_out<T>((float)v * k) : cast_out<T>((float)v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 decode12 (packed.py:92-131).  Fast path: 8 px per lane from three dwords.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(EW_THREADS) void decode12_kernel(const uint8_t* __restrict__ enc,
+                                                              T* __restrict__ out, int64_t n_pairs,
+                                                              int scaled, int ids, float k, int fast) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_groups = fast ? n_pairs / 4 : 0;
+  for (int64_t g = tid; g < n_groups; g += stride) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(enc + g * 12);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t w[4] = {d0 & 0xFFFFFFu, (d0 >> 24) | ((d1 & 0xFFFFu) << 8),
+                           (d1 >> 16) | ((d2 & 0xFFu) << 16), d2 >> 8};
+    T o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t p0, p1;
+      unpack_pair(w[j], ids, p0, p1);
+      o[2 * j] = write_value<T>(p0, scaled, k);
+      o[2 * j + 1] = write_value<T>(p1, scaled, k);
+    }
+    T* dst = out + g * 8;
+    if (sizeof(T) == 1) {
+      *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o);
+    } else if (sizeof(T) == 2) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+    } else {
+      reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(o)[0];
+      reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(o)[1];
+    }
+  }
+  for (int64_t j = n_groups * 4 + tid; j < n_pairs; j += stride) {
+    const uint8_t* q = enc + j * 3;
+    const uint32_t w = q[0] | (q[1] << 8) | (q[2] << 16);
+    uint32_t p0, p1;
+    unpack_pair(w, ids, p0, p1);
+    out[2 * j] = write_value<T>(p0, scaled, k);
+    out[2 * j + 1] = write_value<T>(p1, scaled, k);
+  }
+}
+
+// K2 decode16 (packed.py:135-172)
+template <class T>
+__global__ __launch_bounds__(EW_THREADS) void decode16_kernel(const uint8_t* __restrict__ enc,
+                                                              T* __restrict__ out, int64_t n,
+                                                              int scaled, float k, int fast) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_groups = fast ? n / 8 : 0;
+  for (int64_t g = tid; g < n_groups; g += stride) {
+    const uint4 d = *reinterpret_cast<const uint4*>(enc + g * 16);
+    const uint32_t v[8] = {d.x & 0xFFFFu, d.x >> 16, d.y & 0xFFFFu, d.y >> 16,
+                           d.z & 0xFFFFu, d.z >> 16, d.w & 0xFFFFu, d.w >> 16};
+    T o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = write_value<T>(v[j], scaled, k);
+    T* dst = out + g * 8;
+    if (sizeof(T) == 1) {
+      *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(o);
+    } else if (sizeof(T) == 2) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+    } else {
+      reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(o)[0];
+      reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(o)[1];
+    }
+  }
+  for (int64_t i = n_groups * 8 + tid; i < n; i += stride) {
+    const uint32_t v = enc[2 * i] | (enc[2 * i + 1] << 8);
+    out[i] = write_value<T>(v, scaled, k);
+  }
+}
+
+// K3 encode12 (packed.py:60-89) -- test-input generator, one pair per lane
+template <class T>
+__global__ __launch_bounds__(EW_THREADS) void encode12_kernel(const T* __restrict__ values,
+                                                              uint8_t* __restrict__ enc,
+                                                              int64_t n_pairs, int scaled, int ids,
+                                                              float k) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_pairs; j += stride) {
+    uint32_t p[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float x = (float)values[2 * j + e];
+      if (scaled) {
+        const float r = roundf(x * k);  // ti.round: half away from zero
+        p[e] = (uint32_t)fminf(fmaxf(r, 0.f), 65535.f);
+      } else {
+        p[e] = (uint32_t)values[2 * j + e] & 0xFFFFu;
+      }
+    }
+    uint8_t* q = enc + 3 * j;
+    if (!ids) {  // packed.py:13-20
+      q[0] = p[0] & 0xFF;
+      q[1] = ((p[1] & 0xF) << 4) | ((p[0] >> 8) & 0xFF);
+      q[2] = (p[1] >> 4) & 0xFF;
+    } else {     // packed.py:48-55
+      q[0] = (p[0] >> 4) & 0xFF;
+      q[1] = (p[1] >> 4) & 0xFF;
+      q[2] = ((p[0] & 0xF) << 4) | (p[1] & 0xF);
+    }
+  }
+}
+
+// K11 loaders (camera_isp.py:82-99)
+template <class T>
+__global__ __launch_bounds__(EW_THREADS) void load_convert_kernel(const void* __restrict__ src,
+                                                                  T* __restrict__ dst, int64_t n,
+                                                                  int mode) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float x;
+    if (mode == MI_LOAD_16U) x = (float)static_cast<const uint16_t*>(src)[i] / 65535.0f;
+    else if (mode == MI_LOAD_32F) x = static_cast<const float*>(src)[i];
+    else x = (float)static_cast<const uint16_t*>(src)[i];
+    dst[i] = cast_out<T>(x);
+  }
+}
+
+// K5 rgb_to_bayer (bayer.py:101-112): channel index per site from pixel_orders (bayer.py:85-90)
+template <class T>
+__global__ __launch_bounds__(EW_THREADS) void mosaic_kernel(const T* __restrict__ rgb,
+                                                            T* __restrict__ cfa, int H, int W,
+                                                            int order4) {
+  const int64_t n = (int64_t)H * W;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i / W), c = (int)(i - (int64_t)r * W);
+    const int site = (r & 1) * 2 + (c & 1);          // (r0c0, r0c1, r1c0, r1c1)
+    const int ch = (order4 >> (2 * site)) & 3;
+    cfa[i] = rgb[i * 3 + ch];
+  }
+}
+
+// K6 bilinear (interpolate.py:19-34,59-66)
+template <class TI, class TO>
+__global__ __launch_bounds__(EW_THREADS) void resize_kernel(const TI* __restrict__ src,
+                                                            TO* __restrict__ dst, int Hs, int Ws,
+                                                            int Hd, int Wd, float s0, float s1,
+                                                            float intensity) {
+  const int64_t n = (int64_t)Hd * Wd;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i / Wd), c = (int)(i - (int64_t)r * Wd);
+    const float pr = (float)r / s0, pc = (float)c / s1;
+    const int ir = (int)pr, ic = (int)pc;
+    const float fr = pr - (float)ir, fc = pc - (float)ic;
+    const int r0 = min(max(ir, 0), Hs - 1), r1 = min(max(ir + 1, 0), Hs - 1);
+    const int c0 = min(max(ic, 0), Ws - 1), c1 = min(max(ic + 1, 0), Ws - 1);
+    const TI* a = src + ((size_t)r0 * Ws + c0) * 3;
+    const TI* b = src + ((size_t)r1 * Ws + c0) * 3;
+    const TI* cc = src + ((size_t)r0 * Ws + c1) * 3;
+    const TI* d = src + ((size_t)r1 * Ws + c1) * 3;
+    TO* o = dst + i * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float y1 = (float)a[ch] * (1.0f - fr) + (float)b[ch] * fr;
+      const float y2 = (float)cc[ch] * (1.0f - fr) + (float)d[ch] * fr;
+      o[ch] = cast_out<TO>((y1 * (1.0f - fc) + y2 * fc) * intensity);
+    }
+  }
+}
+
+// interpolate.py:36-54: source index for destination (r, c), shape = destination shape
+MI_DEV void transformed(int Hd, int Wd, int r, int c, int t, int& sr, int& sc) {
+  switch (t) {
+    case MI_T_ROTATE_90: sr = Wd - c - 1; sc = r; break;
+    case MI_T_ROTATE_180: sr = Hd - r - 1; sc = Wd - c - 1; break;
+    case MI_T_ROTATE_270: sr = c; sc = Hd - r - 1; break;
+    case MI_T_TRANSPOSE: sr = c; sc = r; break;
+    case MI_T_FLIP_VERT: sr = Hd - r - 1; sc = c; break;
+    case MI_T_FLIP_HORIZ: sr = r; sc = Wd - c - 1; break;
+    case MI_T_TRANSVERSE: sr = Wd - c - 1; sc = Hd - r - 1; break;
+    default: sr = r; sc = c; break;
+  }
+}
+
+// K7 transform (interpolate.py:93-125)
+template <class T>
+__global__ __launch_bounds__(EW_THREADS) void transform_kernel(const T* __restrict__ src,
+                                                               T* __restrict__ dst, int Hs, int Ws,
+                                                               int Hd, int Wd, int t) {
+  const int64_t n = (int64_t)Hd * Wd;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i / Wd), c = (int)(i - (int64_t)r * Wd);
+    int sr, sc;
+    transformed(Hd, Wd, r, c, t, sr, sc);
+    const T* s = src + ((size_t)sr * Ws + sc) * 3;
+    T* o = dst + i * 3;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 8-pixel (24-element) vector IO on (H, W, 3) images
+// ---------------------------------------------------------------------------------------------
+template <class T> MI_DEV void load24(const T* p, float (&v)[24], int npx, bool vec) {
+  if (vec && npx == 8) {
+    T t[24];
+    if (sizeof(T) == 1) {
+      const uint2* s = reinterpret_cast<const uint2*>(p);
+      uint2* d = reinterpret_cast<uint2*>(t);
+      d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    } else {
+      constexpr int N = (int)(sizeof(T) * 24 / 16);
+      const uint4* s = reinterpret_cast<const uint4*>(p);
+      uint4* d = reinterpret_cast<uint4*>(t);
+#pragma unroll
+      for (int i = 0; i < N; ++i) d[i] = s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) v[i] = (float)t[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) v[i] = i < npx * 3 ? (float)p[i] : 0.f;
+  }
+}
+
+template <class T> MI_DEV void store24(T* p, const float (&v)[24], int npx, bool vec) {
+  T o[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) o[i] = cast_out<T>(v[i]);
+  if (vec && npx == 8) {
+    if (sizeof(T) == 1) {
+      const uint2* s = reinterpret_cast<const uint2*>(o);
+      uint2* d = reinterpret_cast<uint2*>(p);
+      d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    } else {
+      constexpr int N = (int)(sizeof(T) * 24 / 16);
+      const uint4* s = reinterpret_cast<const uint4*>(o);
+      uint4* d = reinterpret_cast<uint4*>(p);
+#pragma unroll
+      for (int i = 0; i < N; ++i) d[i] = s[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 24; ++i)
+      if (i < npx * 3) p[i] = o[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic RGB-image pass used by the stateless tonemaps (tonemap.py) and the ISP tonemaps
+// (camera_isp.py:177-227).  MODE selects the per-pixel work; reductions leave one partial per
+// block.
+// ---------------------------------------------------------------------------------------------
+enum PassMode {
+  PM_MINMAX = 0,        // bounds_func (util.py:50-60)
+  PM_STATS = 1,         // linear_func(gamma 1) + metering_func (tonemap.py:78-103)
+  PM_RH_MINMAX = 2,     // + reinhard_func, bounds of the result (tonemap.py:150-153)
+  PM_RH_STORE = 3,      // + final linear_func (tonemap.py:154)
+  PM_LINEAR_STORE = 4,  // tonemap_linear / ISP linear_kernel: linear_func straight to dst
+  PM_ISP_RH_P1 = 5,     // camera_isp.py:198-213: p written back in place, max(p)
+  PM_ISP_RH_P2 = 6      // camera_isp.py:215-218: (p/max_out)^(1/gamma)*255 -> u8
+};
+
+struct PassArgs {
+  const void* src; void* dst; void* inplace;
+  const float* fp; float* partials; int part_stride;
+  int64_t n_px;
+  int vec_in, vec_out;
+  float gamma_inv, la, ca, out_scale;
+  int transform, H, W;      // optional orientation transform fused into the store (u8 ISP outputs)
+};
+
+template <class TI, class TO, int MODE>
+__global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) {
+#pragma clang fp contract(fast)
+  __shared__ float red[4][8];
+  const TI* src = static_cast<const TI*>(a.src);
+  TO* dst = static_cast<TO*>(a.dst);
+  const int64_t n_groups = (a.n_px + 7) / 8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+
+  float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f, maxout_inv = 1.f;
+  ReinhardK rk;
+  rk.la = a.la; rk.ca = a.ca; rk.map_key = 1.f; rk.ei = 1.f; rk.mean3[0] = rk.mean3[1] = rk.mean3[2] = 0.f;
+  if (MODE != PM_MINMAX && MODE != PM_ISP_RH_P2) { lo = a.fp[FP_LO]; inv = a.fp[FP_INV]; }
+  if (MODE == PM_RH_MINMAX || MODE == PM_RH_STORE || MODE == PM_ISP_RH_P1) {
+    rk.map_key = a.fp[FP_MAPKEY]; rk.ei = a.fp[FP_EI];
+    rk.mean3[0] = a.fp[FP_MEAN3]; rk.mean3[1] = a.fp[FP_MEAN3 + 1]; rk.mean3[2] = a.fp[FP_MEAN3 + 2];
+  }
+  if (MODE == PM_RH_STORE) { lo2 = a.fp[FP_LO2]; inv2 = a.fp[FP_INV2]; }
+  if (MODE == PM_ISP_RH_P2) maxout_inv = 1.0f / a.fp[FP_MAXOUT];
+
+  float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  StatsAcc st; st.init();
+
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
+    const int64_t px0 = g * 8;
+    const int npx = (int)(a.n_px - px0 < 8 ? a.n_px - px0 : 8);
+    float v[24], o[24];
+    load24<TI>(src + px0 * 3, v, npx, a.vec_in);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool live = k < npx;
+      float x[3] = {v[3 * k], v[3 * k + 1], v[3 * k + 2]};
+      if (MODE == PM_MINMAX) {
+        if (live) {
+          vmin = fminf(vmin, fminf(x[0], fminf(x[1], x[2])));
+          vmax = fmaxf(vmax, fmaxf(x[0], fmaxf(x[1], x[2])));
+        }
+      } else if (MODE == PM_LINEAR_STORE) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = linear_px(x[ch], lo, inv, a.gamma_inv, a.out_scale);
+      } else if (MODE == PM_ISP_RH_P1) {
+        // camera_isp.py:200: no clamp on the normalised value here
+        float t[3], q[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) t[ch] = (x[ch] - lo) * inv;
+        reinhard_px(t, rk, q);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = q[ch];
+        if (live) vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
+      } else if (MODE == PM_ISP_RH_P2) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          float q = x[ch] * maxout_inv;
+          if (a.gamma_inv != 1.f) q = hw_pow(q, a.gamma_inv);
+          o[3 * k + ch] = 255.f * q;
+        }
+      } else {
+        float t[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) t[ch] = norm01(x[ch], lo, inv);
+        if (MODE == PM_STATS) {
+          if (live) st.add(t[0], t[1], t[2]);
+        } else {
+          float q[3];
+          reinhard_px(t, rk, q);
+          if (MODE == PM_RH_MINMAX) {
+            if (live) {
+              vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
+              vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
+            }
+          } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = linear_px(q[ch], lo2, inv2, a.gamma_inv, a.out_scale);
+          }
+        }
+      }
+    }
+    if (MODE == PM_ISP_RH_P1) {
+      store24<TI>(static_cast<TI*>(a.inplace) + px0 * 3, o, npx, a.vec_in);
+    } else if (MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2) {
+      if (a.transform == MI_T_NONE) {
+        store24<TO>(dst + px0 * 3, o, npx, a.vec_out);
+      } else {
+        // scatter: source pixel (r, c) -> the destination pixel that reads it (inverse of
+        // interpolate.py:36-54); destination dims (Hd, Wd)
+        const bool swap = a.transform == MI_T_ROTATE_90 || a.transform == MI_T_ROTATE_270 ||
+                          a.transform == MI_T_TRANSPOSE;
+        const int Hd = swap ? a.W : a.H, Wd = swap ? a.H : a.W;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (k >= npx) break;
+          const int64_t px = px0 + k;
+          const int r = (int)(px / a.W), c = (int)(px - (int64_t)r * a.W);
+          int dr, dc;
+          switch (a.transform) {
+            case MI_T_ROTATE_90: dr = c; dc = Wd - 1 - r; break;        // sr = Wd-c'-1, sc = r'
+            case MI_T_ROTATE_180: dr = Hd - 1 - r; dc = Wd - 1 - c; break;
+            case MI_T_ROTATE_270: dr = Hd - 1 - c; dc = r; break;       // sr = c', sc = Hd-r'-1
+            case MI_T_TRANSPOSE: dr = c; dc = r; break;
+            case MI_T_FLIP_VERT: dr = Hd - 1 - r; dc = c; break;
+            case MI_T_FLIP_HORIZ: dr = r; dc = Wd - 1 - c; break;
+            default: dr = Hd - 1 - c; dc = Wd - 1 - r; break;           // transverse (square only)
+          }
+          TO* q = dst + ((size_t)dr * Wd + dc) * 3;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) q[ch] = cast_out<TO>(o[3 * k + ch]);
+        }
+      }
+    }
+  }
+
+  if (MODE == PM_MINMAX || MODE == PM_RH_MINMAX || MODE == PM_ISP_RH_P1) {
+    const float v2[2] = {vmin, vmax};
+    const int op[2] = {0, 1};
+    block_reduce_store<2>(v2, op, red, a.partials, a.part_stride, blockIdx.x);
+  } else if (MODE == PM_STATS) {
+    const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
+    const int op[7] = {0, 1, 2, 2, 2, 2, 2};
+    block_reduce_store<7>(v7, op, red, a.partials, a.part_stride, blockIdx.x);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 metering on the stride-subsampled images (camera_isp.py:142-175), two data passes.
+// grid = (blocks_per_image, n_images); partial index = blockIdx.y * gridDim.x + blockIdx.x + base
+// ---------------------------------------------------------------------------------------------
+template <class T, int PHASE>
+__global__ __launch_bounds__(EW_THREADS) void metering_kernel(const ew::PtrList imgs, int H, int W,
+                                                              int stride, const float* bounds,
+                                                              float* partials, int part_stride,
+                                                              int part_base) {
+#pragma clang fp contract(fast)
+  __shared__ float red[4][8];
+  const T* img = static_cast<const T*>(imgs.p[blockIdx.y]);
+  const int hs = (H + stride - 1) / stride, ws = (W + stride - 1) / stride;
+  const int n = hs * ws;
+  float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  StatsAcc st; st.init();
+  float bmin = 0.f, dinv = 1.f;
+  if (PHASE == 1) {
+    bmin = bounds[0];
+    dinv = 1.0f / (bounds[1] - bounds[0] + 1e-6f);   // camera_isp.py:119
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int sr = i / ws, sc = i - sr * ws;
+    const T* p = img + ((size_t)(sr * stride) * W + (size_t)sc * stride) * 3;
+    const float x0 = (float)p[0], x1 = (float)p[1], x2 = (float)p[2];
+    if (PHASE == 0) {
+      vmin = fminf(vmin, fminf(x0, fminf(x1, x2)));
+      vmax = fmaxf(vmax, fmaxf(x0, fmaxf(x1, x2)));
+    } else {
+      st.add((x0 - bmin) * dinv, (x1 - bmin) * dinv, (x2 - bmin) * dinv);
+    }
+  }
+  const int block = part_base + blockIdx.y * gridDim.x + blockIdx.x;
+  if (PHASE == 0) {
+    const float v2[2] = {vmin, vmax};
+    const int op[2] = {0, 1};
+    block_reduce_store<2>(v2, op, red, partials, part_stride, block);
+  } else {
+    const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
+    const int op[7] = {0, 1, 2, 2, 2, 2, 2};
+    block_reduce_store<7>(v7, op, red, partials, part_stride, block);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: one block folds the per-block partials (sums in fp64) and thread 0 derives the
+// scalars of the next pass with the accurate libm-grade functions.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void finalize_kernel(int mode, const ew::FinArgs a) {
+  __shared__ double sh[7][EW_THREADS / 64];
+  __shared__ double tot[7];
+  const int nrows = (mode == ew::FIN_STATS || mode == ew::FIN_ISP_STATS || mode == ew::FIN_ISP_SUMS) ? 7 : 2;
+  for (int k = 0; k < nrows; ++k) {
+    const int op = k == 0 ? 0 : (k == 1 ? 1 : 2);
+    double acc = op == 0 ? (double)__builtin_inff() : (op == 1 ? -(double)__builtin_inff() : 0.0);
+    for (int i = threadIdx.x; i < a.nblocks; i += blockDim.x) {
+      const double v = (double)a.partials[(size_t)k * a.stride + i];
+      if (op == 0) acc = fmin(acc, v);
+      else if (op == 1) acc = fmax(acc, v);
+      else acc += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double other = __shfl_xor(acc, o, 64);
+      acc = op == 0 ? fmin(acc, other) : (op == 1 ? fmax(acc, other) : acc + other);
+    }
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < nrows) {
+    const int k = threadIdx.x;
+    const int op = k == 0 ? 0 : (k == 1 ? 1 : 2);
+    double acc = sh[k][0];
+    for (int w = 1; w < EW_THREADS / 64; ++w)
+      acc = op == 0 ? fmin(acc, sh[k][w]) : (op == 1 ? fmax(acc, sh[k][w]) : acc + sh[k][w]);
+    tot[k] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+
+  const float lo = (float)tot[0], hi = (float)tot[1];
+  float* fp = a.fp;
+  switch (mode) {
+    case ew::FIN_BOUNDS:
+      fp[FP_LO] = lo; fp[FP_HI] = hi; fp[FP_INV] = 1.0f / (hi - lo);   // tonemap.py:13
+      break;
+    case ew::FIN_BOUNDS2:
+      fp[FP_LO2] = lo; fp[FP_HI2] = hi; fp[FP_INV2] = 1.0f / (hi - lo);
+      break;
+    case ew::FIN_MAXOUT:
+      fp[FP_MAXOUT] = fmaxf(1e-6f, hi);                               // camera_isp.py:190,213
+      break;
+    case ew::FIN_RAW_BOUNDS:
+      a.out[0] = lo; a.out[1] = hi;
+      break;
+    case ew::FIN_ISP_BOUNDS: {
+      // camera_isp.py:156-157: b = lerp(alpha, new, prev) = new + alpha * (prev - new)
+      const float pmin = a.state9[0], pmax = a.state9[1];
+      fp[FP_LO] = lo + a.alpha * (pmin - lo);
+      fp[FP_HI] = hi + a.alpha * (pmax - hi);
+      break;
+    }
+    default: {
+      const float LN2 = 0.6931471805599453f;
+      const float lmin = logf(lo), lmax = logf(hi);      // lo/hi here are min/max of max(gray,1e-4)
+      const float slog = (float)(tot[2] * 0.6931471805599453);
+      const float sgray = (float)tot[3];
+      const float s0 = (float)tot[4], s1 = (float)tot[5], s2 = (float)tot[6];
+      (void)LN2;
+      if (mode == ew::FIN_ISP_SUMS) {
+        a.out[0] = lmin; a.out[1] = lmax; a.out[2] = slog; a.out[3] = sgray;
+        a.out[4] = s0; a.out[5] = s1; a.out[6] = s2; a.out[7] = a.n_px;
+      } else if (mode == ew::FIN_ISP_STATS) {
+        // camera_isp.py:131-134,164-166
+        const float n = a.n_px;
+        const float* b = a.bounds_in ? a.bounds_in : fp + FP_LO;
+        const float v[9] = {b[0], b[1], lmin, lmax, slog / n, sgray / n, s0 / n, s1 / n, s2 / n};
+        for (int i = 0; i < 9; ++i) a.state9[i] = v[i] + a.alpha * (a.state9[i] - v[i]);
+      } else {
+        // tonemap.py:99-103 (log_bounds = (lmin, -lmax): reference sign quirk), :115-119
+        const float n = a.n_px;
+        const float Bmin = lmin, Bmax = -lmax;
+        const float lmean = slog / n, gmean = sgray / n;
+        const float rm[3] = {s0 / n, s1 / n, s2 / n};
+        const float key = (Bmax - lmean) / (Bmax - Bmin);
+        fp[FP_BMIN] = Bmin; fp[FP_BMAX] = Bmax; fp[FP_LMEAN] = lmean; fp[FP_GMEAN] = gmean;
+        fp[FP_RMEAN] = rm[0]; fp[FP_RMEAN + 1] = rm[1]; fp[FP_RMEAN + 2] = rm[2];
+        fp[FP_MAPKEY] = 0.3f + 0.7f * powf(key, 1.4f);
+        fp[FP_EI] = expf(-a.intensity);
+        for (int c = 0; c < 3; ++c) fp[FP_MEAN3 + c] = gmean + a.ca * (rm[c] - gmean);
+      }
+      break;
+    }
+  }
+}
+
+__global__ void isp_reinhard_prep_kernel(const float* state9, float* fp, float intensity, float ca) {
+  // camera_isp.py:186-195
+  const float bmin = state9[0], bmax = state9[1], lmin = state9[2], lmax = state9[3];
+  const float lmean = state9[4], mean = state9[5];
+  const float key = (lmax - lmean) / (lmax - lmin);
+  fp[FP_LO] = bmin; fp[FP_HI] = bmax; fp[FP_INV] = 1.0f / (bmax - bmin);
+  fp[FP_MAPKEY] = 0.3f + 0.7f * powf(key, 1.4f);
+  fp[FP_EI] = expf(-intensity);
+  for (int c = 0; c < 3; ++c) fp[FP_MEAN3 + c] = mean + ca * (state9[6 + c] - mean);
+}
+
+}  // namespace
+
+// =================================================================================================
+// internal launch interface
+// =================================================================================================
+namespace ew {
+
+int finalize(int mode, const FinArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(EW_THREADS), 0, s, mode, a);
+  MI_LAUNCH_CHECK();
+  return 0;
+}
+
+int isp_reinhard_prep(const float* state9, float* fp, float intensity, float ca, hipStream_t s) {
+  hipLaunchKernelGGL(isp_reinhard_prep_kernel, dim3(1), dim3(1), 0, s, state9, fp, intensity, ca);
+  MI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <class TI, class TO>
+static int launch_pass_t(int mode, const PassArgs& a, int nblocks, hipStream_t s) {
+#define MI_PASS(M)                                                                              \
+  case M:                                                                                       \
+    hipLaunchKernelGGL((rgb_pass_kernel<TI, TO, M>), dim3(nblocks), dim3(EW_THREADS), 0, s, a); \
+    break;
+  switch (mode) {
+    MI_PASS(PM_MINMAX) MI_PASS(PM_STATS) MI_PASS(PM_RH_MINMAX) MI_PASS(PM_RH_STORE)
+    MI_PASS(PM_LINEAR_STORE) MI_PASS(PM_ISP_RH_P1) MI_PASS(PM_ISP_RH_P2)
+    default: mi_set_error("bad pass mode %d", mode); return 1;
+  }
+#undef MI_PASS
+  MI_LAUNCH_CHECK();
+  return 0;
+}
+
+// number of blocks an RGB pass over n_px pixels uses (== number of partials it leaves)
+static int pass_blocks(int64_t n_px, int cap) {
+  int64_t groups = (n_px + 7) / 8;
+  int64_t b = (groups + EW_THREADS - 1) / EW_THREADS;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+static int launch_pass(int mode, int in_dtype, int out_dtype, const PassArgs& a, int nblocks, hipStream_t s) {
+  // instantiate the (in, out) pairs the API can produce: reductions ignore TO
+  const bool reduce_only = mode == PM_MINMAX || mode == PM_STATS || mode == PM_RH_MINMAX || mode == PM_ISP_RH_P1;
+  if (reduce_only) out_dtype = MI_U8;
+  switch (in_dtype) {
+#define MI_IN(DT, TI)                                                                    \
+  case DT:                                                                               \
+    switch (out_dtype) {                                                                 \
+      case MI_U8: return launch_pass_t<TI, uint8_t>(mode, a, nblocks, s);                \
+      case MI_U16: return launch_pass_t<TI, uint16_t>(mode, a, nblocks, s);              \
+      case MI_F16: return launch_pass_t<TI, half_t>(mode, a, nblocks, s);                \
+      default: return launch_pass_t<TI, float>(mode, a, nblocks, s);                     \
+    }
+    MI_IN(MI_U8, uint8_t)
+    MI_IN(MI_U16, uint16_t)
+    MI_IN(MI_F16, half_t)
+    default:
+      switch (out_dtype) {
+        case MI_U8: return launch_pass_t<float, uint8_t>(mode, a, nblocks, s);
+        case MI_U16: return launch_pass_t<float, uint16_t>(mode, a, nblocks, s);
+        case MI_F16: return launch_pass_t<float, half_t>(mode, a, nblocks, s);
+        default: return launch_pass_t<float, float>(mode, a, nblocks, s);
+      }
+#undef MI_IN
+  }
+}
+
+}  // namespace ew
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace ew;
+
+extern "C" int mi_isp_decode12(const uint8_t* enc, void* out, int64_t n_px, int out_dtype, int scaled,
+                               int ids_format, void* stream) {
+  MI_REQUIRE(enc && out, "decode12: null pointer");
+  MI_REQUIRE(n_px >= 0 && n_px % 2 == 0, "decode12: pixel count must be even, got %lld", (long long)n_px);
+  MI_REQUIRE(mi_valid_dtype(out_dtype), "decode12: bad dtype %d", out_dtype);
+  if (n_px == 0) return 0;
+  const float k = (float)((double)mi_scale_factor(out_dtype) / 4095.0);
+  const int fast = mi_aligned(enc, 4) && mi_aligned(out, 16);
+  const int64_t n_pairs = n_px / 2;
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_dtype(out_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((decode12_kernel<T>), dim3(grid_for((n_pairs + 3) / 4)), dim3(EW_THREADS), 0, s, enc,
+                       static_cast<T*>(out), n_pairs, scaled, ids_format, k, fast);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+extern "C" int mi_isp_decode16(const uint8_t* enc, void* out, int64_t n_px, int out_dtype, int scaled,
+                               void* stream) {
+  MI_REQUIRE(enc && out, "decode16: null pointer");
+  MI_REQUIRE(n_px >= 0, "decode16: negative count");
+  MI_REQUIRE(mi_valid_dtype(out_dtype), "decode16: bad dtype %d", out_dtype);
+  if (n_px == 0) return 0;
+  const float k = (float)((double)mi_scale_factor(out_dtype) / 65535.0);
+  const int fast = mi_aligned(enc, 16) && mi_aligned(out, 16);
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_dtype(out_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((decode16_kernel<T>), dim3(grid_for((n_px + 7) / 8)), dim3(EW_THREADS), 0, s, enc,
+                       static_cast<T*>(out), n_px, scaled, k, fast);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+extern "C" int mi_isp_encode12(const void* values, uint8_t* enc, int64_t n_px, int in_dtype, int scaled,
+                               int ids_format, void* stream) {
+  MI_REQUIRE(values && enc, "encode12: null pointer");
+  MI_REQUIRE(n_px >= 0 && n_px % 2 == 0, "encode12: pixel count must be even, got %lld", (long long)n_px);
+  MI_REQUIRE(mi_valid_dtype(in_dtype), "encode12: bad dtype %d", in_dtype);
+  if (n_px == 0) return 0;
+  const float k = (float)(4095.0 / (double)mi_scale_factor(in_dtype));
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_dtype(in_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((encode12_kernel<T>), dim3(grid_for(n_px / 2)), dim3(EW_THREADS), 0, s,
+                       static_cast<const T*>(values), enc, n_px / 2, scaled, ids_format, k);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+extern "C" int mi_isp_load_convert(const void* src, void* dst, int64_t n, int mode, int out_dtype, void* stream) {
+  MI_REQUIRE(src && dst, "load_convert: null pointer");
+  MI_REQUIRE(mode >= MI_LOAD_16U && mode <= MI_LOAD_16F, "load_convert: bad mode %d", mode);
+  MI_REQUIRE(out_dtype == MI_F16 || out_dtype == MI_F32, "load_convert: output must be f16/f32");
+  if (n <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_dtype(out_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((load_convert_kernel<T>), dim3(grid_for(n)), dim3(EW_THREADS), 0, s, src,
+                       static_cast<T*>(dst), n, mode);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+extern "C" int mi_isp_mosaic(const void* rgb, void* cfa, int H, int W, int dtype, int pattern, void* stream) {
+  MI_REQUIRE(rgb && cfa, "mosaic: null pointer");
+  MI_REQUIRE(H > 0 && W > 0, "mosaic: bad shape %dx%d", H, W);
+  MI_REQUIRE(mi_valid_dtype(dtype), "mosaic: bad dtype %d", dtype);
+  MI_REQUIRE(pattern >= 0 && pattern <= 3, "mosaic: bad pattern %d", pattern);
+  // bayer.py:85-90 pixel_orders as (r0c0, r0c1, r1c0, r1c1), 2 bits each
+  static const int orders[4][4] = {{0, 1, 1, 2}, {1, 0, 2, 1}, {1, 2, 0, 1}, {2, 1, 1, 0}};
+  int order4 = 0;
+  for (int i = 0; i < 4; ++i) order4 |= orders[pattern][i] << (2 * i);
+  hipStream_t s = (hipStream_t)stream;
+  // the reference loops over whole 2x2 quads only (bayer.py:106): odd trailing row/col untouched
+  const int He = H & ~1, We = W & ~1;
+  MI_REQUIRE(He == H && We == W, "mosaic: image must be even size, got %dx%d", H, W);
+  return dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((mosaic_kernel<T>), dim3(grid_for((int64_t)H * W)), dim3(EW_THREADS), 0, s,
+                       static_cast<const T*>(rgb), static_cast<T*>(cfa), H, W, order4);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+extern "C" int mi_isp_resize_bilinear(const void* src, void* dst, int Hs, int Ws, int Hd, int Wd, float s0,
+                                      float s1, int in_dtype, int out_dtype, void* stream) {
+  MI_REQUIRE(src && dst, "resize: null pointer");
+  MI_REQUIRE(Hs > 0 && Ws > 0 && Hd >= 0 && Wd >= 0, "resize: bad shape");
+  MI_REQUIRE(s0 > 0.f && s1 > 0.f, "resize: scale must be positive");
+  MI_REQUIRE(mi_valid_dtype(in_dtype) && mi_valid_dtype(out_dtype), "resize: bad dtype");
+  if ((int64_t)Hd * Wd == 0) return 0;
+  const float intensity = (float)((double)mi_scale_factor(out_dtype) / (double)mi_scale_factor(in_dtype));
+  hipStream_t s = (hipStream_t)stream;
+  const int g = grid_for((int64_t)Hd * Wd);
+  return dispatch_dtype(in_dtype, [&](auto ti) {
+    using TI = decltype(ti);
+    return dispatch_dtype(out_dtype, [&](auto to) {
+      using TO = decltype(to);
+      hipLaunchKernelGGL((resize_kernel<TI, TO>), dim3(g), dim3(EW_THREADS), 0, s, static_cast<const TI*>(src),
+                         static_cast<TO*>(dst), Hs, Ws, Hd, Wd, s0, s1, intensity);
+      MI_LAUNCH_CHECK();
+      return 0;
+    });
+  });
+}
+
+extern "C" int mi_isp_transform(const void* src, void* dst, int Hs, int Ws, int dtype, int transform, void* stream) {
+  MI_REQUIRE(src && dst, "transform: null pointer");
+  MI_REQUIRE(Hs > 0 && Ws > 0, "transform: bad shape");
+  MI_REQUIRE(mi_valid_dtype(dtype), "transform: bad dtype");
+  MI_REQUIRE(transform >= MI_T_NONE && transform <= MI_T_TRANSVERSE, "transform: bad transform %d", transform);
+  MI_REQUIRE(transform != MI_T_TRANSVERSE || Hs == Ws,
+             "transform: transverse is only defined for square images (the reference reads out of bounds)");
+  const bool swap = transform == MI_T_ROTATE_90 || transform == MI_T_ROTATE_270 || transform == MI_T_TRANSPOSE;
+  const int Hd = swap ? Ws : Hs, Wd = swap ? Hs : Ws;
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((transform_kernel<T>), dim3(grid_for((int64_t)Hd * Wd)), dim3(EW_THREADS), 0, s,
+                       static_cast<const T*>(src), static_cast<T*>(dst), Hs, Ws, Hd, Wd, transform);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+// ---- metering --------------------------------------------------------------------------------
+static int metering_pass(int phase, const void* const* images, int n_images, int H, int W, int stride,
+                         int dtype, const float* bounds, float* partials, int cap, int* nblocks_out,
+                         hipStream_t s) {
+  const int hs = (H + stride - 1) / stride, ws = (W + stride - 1) / stride;
+  int bpi = (hs * ws + EW_THREADS * 4 - 1) / (EW_THREADS * 4);
+  if (bpi < 1) bpi = 1;
+  if (bpi > 16) bpi = 16;
+  MI_REQUIRE((int64_t)bpi * n_images <= cap, "metering: too many images (%d) for the workspace", n_images);
+  int base = 0;
+  for (int i0 = 0; i0 < n_images; i0 += 64) {
+    PtrList pl;
+    const int n = n_images - i0 < 64 ? n_images - i0 : 64;
+    for (int i = 0; i < 64; ++i) pl.p[i] = i < n ? images[i0 + i] : nullptr;
+    const int rc = dispatch_dtype(dtype, [&](auto tag) {
+      using T = decltype(tag);
+      if (phase == 0)
+        hipLaunchKernelGGL((metering_kernel<T, 0>), dim3(bpi, n), dim3(EW_THREADS), 0, s, pl, H, W, stride, bounds,
+                           partials, cap, base);
+      else
+        hipLaunchKernelGGL((metering_kernel<T, 1>), dim3(bpi, n), dim3(EW_THREADS), 0, s, pl, H, W, stride, bounds,
+                           partials, cap, base);
+      MI_LAUNCH_CHECK();
+      return 0;
+    });
+    if (rc) return rc;
+    base += bpi * n;
+  }
+  *nblocks_out = base;
+  return 0;
+}
+
+static int metering_check(const void* const* images, int n_images, int H, int W, int stride, int dtype,
+                          const void* ws) {
+  MI_REQUIRE(images && ws, "metering: null pointer");
+  MI_REQUIRE(n_images > 0, "metering: need at least one image");
+  for (int i = 0; i < n_images; ++i) MI_REQUIRE(images[i], "metering: image %d is null", i);
+  MI_REQUIRE(H > 0 && W > 0 && stride > 0, "metering: bad shape/stride");
+  MI_REQUIRE(mi_valid_dtype(dtype), "metering: bad dtype");
+  return 0;
+}
+
+extern "C" int mi_isp_metering_bounds(const void* const* images, int n_images, int H, int W, int stride, int dtype,
+                                      float* out2, void* ws, void* stream) {
+  if (int rc = metering_check(images, n_images, H, W, stride, dtype, ws)) return rc;
+  MI_REQUIRE(out2, "metering_bounds: null output");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  int nb = 0;
+  if (int rc = metering_pass(0, images, n_images, H, W, stride, dtype, nullptr, partials, cap, &nb, s)) return rc;
+  FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp; fa.out = out2;
+  return finalize(FIN_RAW_BOUNDS, fa, s);
+}
+
+extern "C" int mi_isp_metering_sums(const void* const* images, int n_images, int H, int W, int stride, int dtype,
+                                    const float* bounds2, float* out8, void* ws, void* stream) {
+  if (int rc = metering_check(images, n_images, H, W, stride, dtype, ws)) return rc;
+  MI_REQUIRE(bounds2 && out8, "metering_sums: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  int nb = 0;
+  if (int rc = metering_pass(1, images, n_images, H, W, stride, dtype, bounds2, partials, cap, &nb, s)) return rc;
+  const int hs = (H + stride - 1) / stride, wss = (W + stride - 1) / stride;
+  FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp; fa.out = out8;
+  fa.n_px = (float)((int64_t)n_images * hs * wss);
+  return finalize(FIN_ISP_SUMS, fa, s);
+}
+
+extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype,
+                               float* state9, float alpha, void* ws, void* stream) {
+  if (int rc = metering_check(images, n_images, H, W, stride, dtype, ws)) return rc;
+  MI_REQUIRE(state9, "metering: null state");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  int nb = 0;
+  if (int rc = metering_pass(0, images, n_images, H, W, stride, dtype, nullptr, partials, cap, &nb, s)) return rc;
+  FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp; fa.state9 = state9; fa.alpha = alpha;
+  if (int rc = finalize(FIN_ISP_BOUNDS, fa, s)) return rc;
+  if (int rc = metering_pass(1, images, n_images, H, W, stride, dtype, fp + FP_LO, partials, cap, &nb, s)) return rc;
+  const int hs = (H + stride - 1) / stride, wss = (W + stride - 1) / stride;
+  fa.nblocks = nb;
+  fa.n_px = (float)((int64_t)n_images * hs * wss);
+  return finalize(FIN_ISP_STATS, fa, s);
+}
+
+// ---- ISP tonemaps ----------------------------------------------------------------------------
+static bool vec_ok(const void* p, int dtype) { return mi_aligned(p, dtype == MI_U8 ? 8 : 16); }
+
+extern "C" int mi_isp_reinhard(void* image, uint8_t* out, int H, int W, int dtype, const float* state9, float gamma,
+                               float intensity, float light_adapt, float color_adapt, int transform, void* ws,
+                               void* stream) {
+  MI_REQUIRE(image && out && state9 && ws, "reinhard: null pointer");
+  MI_REQUIRE(H > 0 && W > 0, "reinhard: bad shape");
+  MI_REQUIRE(dtype == MI_F16 || dtype == MI_F32, "reinhard: image must be f16 or f32");
+  MI_REQUIRE(gamma > 0.f, "reinhard: gamma must be positive");
+  MI_REQUIRE(transform >= MI_T_NONE && transform <= MI_T_TRANSVERSE, "reinhard: bad transform");
+  MI_REQUIRE(transform != MI_T_TRANSVERSE || H == W, "reinhard: transverse needs a square image");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  if (int rc = isp_reinhard_prep(state9, fp, intensity, color_adapt, s)) return rc;
+  PassArgs a = {};
+  a.src = image; a.inplace = image; a.dst = out; a.fp = fp; a.partials = partials; a.part_stride = cap;
+  a.n_px = (int64_t)H * W; a.vec_in = vec_ok(image, dtype); a.vec_out = vec_ok(out, MI_U8);
+  a.gamma_inv = (float)(1.0 / (double)gamma); a.la = light_adapt; a.ca = color_adapt; a.out_scale = 255.f;
+  a.transform = transform; a.H = H; a.W = W;
+  const int nb = pass_blocks(a.n_px, cap);
+  if (int rc = launch_pass(PM_ISP_RH_P1, dtype, MI_U8, a, nb, s)) return rc;
+  FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
+  if (int rc = finalize(FIN_MAXOUT, fa, s)) return rc;
+  return launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s);
+}
+
+extern "C" int mi_isp_linear(const void* image, uint8_t* out, int H, int W, int dtype, const float* state9,
+                             float gamma, int transform, void* ws, void* stream) {
+  MI_REQUIRE(image && out && state9 && ws, "linear: null pointer");
+  MI_REQUIRE(H > 0 && W > 0, "linear: bad shape");
+  MI_REQUIRE(dtype == MI_F16 || dtype == MI_F32, "linear: image must be f16 or f32");
+  MI_REQUIRE(gamma > 0.f, "linear: gamma must be positive");
+  MI_REQUIRE(transform >= MI_T_NONE && transform <= MI_T_TRANSVERSE, "linear: bad transform");
+  MI_REQUIRE(transform != MI_T_TRANSVERSE || H == W, "linear: transverse needs a square image");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  // FP_LO / FP_INV from the metering bounds state9[0..1] (camera_isp.py:226-227, tonemap.py:13)
+  if (int rc = isp_reinhard_prep(state9, fp, 0.f, 0.f, s)) return rc;
+  PassArgs a = {};
+  a.src = image; a.dst = out; a.fp = fp; a.n_px = (int64_t)H * W;
+  a.vec_in = vec_ok(image, dtype); a.vec_out = vec_ok(out, MI_U8);
+  a.gamma_inv = (float)(1.0 / (double)gamma); a.out_scale = 255.f;
+  a.transform = transform; a.H = H; a.W = W;
+  return launch_pass(PM_LINEAR_STORE, dtype, MI_U8, a, pass_blocks(a.n_px, 1 << 30), s);
+}
+
+// ---- stateless tonemaps (tonemap.py) --------------------------------------------------------------
+static int tonemap_check(const void* src, const void* dst, int H, int W, int in_dtype, int out_dtype, float gamma,
+                         const void* ws) {
+  MI_REQUIRE(src && dst && ws, "tonemap: null pointer");
+  MI_REQUIRE(H > 0 && W > 0, "tonemap: bad shape");
+  MI_REQUIRE(mi_valid_dtype(in_dtype) && mi_valid_dtype(out_dtype), "tonemap: bad dtype");
+  MI_REQUIRE(gamma > 0.f, "tonemap: gamma must be positive");
+  return 0;
+}
+
+extern "C" int mi_isp_tonemap_linear(const void* src, void* dst, int H, int W, int in_dtype, int out_dtype,
+                                     float gamma, void* ws, void* stream) {
+  if (int rc = tonemap_check(src, dst, H, W, in_dtype, out_dtype, gamma, ws)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  PassArgs a = {};
+  a.src = src; a.dst = dst; a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
+  a.vec_in = vec_ok(src, in_dtype); a.vec_out = vec_ok(dst, out_dtype);
+  a.gamma_inv = 1.0f / gamma;                      // tonemap.py:16: 1/gamma evaluated in f32
+  a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
+  const int nb = pass_blocks(a.n_px, cap);
+  if (int rc = launch_pass(PM_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;
+  FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
+  if (int rc = finalize(FIN_BOUNDS, fa, s)) return rc;
+  return launch_pass(PM_LINEAR_STORE, in_dtype, out_dtype, a, nb, s);
+}
+
+extern "C" int mi_isp_tonemap_reinhard(const void* src, void* dst, int H, int W, int in_dtype, int out_dtype,
+                                       float gamma, float intensity, float light_adapt, float color_adapt,
+                                       void* ws, void* stream) {
+  if (int rc = tonemap_check(src, dst, H, W, in_dtype, out_dtype, gamma, ws)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  PassArgs a = {};
+  a.src = src; a.dst = dst; a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
+  a.vec_in = vec_ok(src, in_dtype); a.vec_out = vec_ok(dst, out_dtype);
+  a.gamma_inv = 1.0f / gamma; a.la = light_adapt; a.ca = color_adapt;
+  a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
+  const int nb = pass_blocks(a.n_px, cap);
+  FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
+  fa.n_px = (float)a.n_px; fa.intensity = intensity; fa.la = light_adapt; fa.ca = color_adapt;
+  if (int rc = launch_pass(PM_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;      // tonemap.py:146
+  if (int rc = finalize(FIN_BOUNDS, fa, s)) return rc;
+  if (int rc = launch_pass(PM_STATS, in_dtype, out_dtype, a, nb, s)) return rc;       // :147-149
+  if (int rc = finalize(FIN_STATS, fa, s)) return rc;
+  if (int rc = launch_pass(PM_RH_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;   // :150,153
+  if (int rc = finalize(FIN_BOUNDS2, fa, s)) return rc;
+  return launch_pass(PM_RH_STORE, in_dtype, out_dtype, a, nb, s);                      // :154
+}

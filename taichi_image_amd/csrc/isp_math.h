@@ -1,0 +1,73 @@
+// Per-pixel tonemap arithmetic shared by the fused tile kernels and the elementwise kernels.
+// Restates tonemap.py:12-17,78-131 and camera_isp.py:117-128,186-218 of the reference.
+// Transcendentals use the gfx950 hardware units (v_log_f32 / v_exp_f32 / v_rcp_f32, <= 1 ulp):
+// these stages carry the 1e-4 relative tolerance of the parity contract, not bit-exactness.
+#pragma once
+#include "isp_common.h"
+
+#pragma clang fp contract(fast)
+
+MI_DEV float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
+MI_DEV float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+MI_DEV float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// pow for the bases that occur here: b == 0 -> 0 (e > 0), b < 0 -> NaN, like powf.
+MI_DEV float hw_pow(float b, float e) { return hw_exp2(e * hw_log2(b)); }
+MI_DEV float hw_log(float x) { return hw_log2(x) * 0.6931471805599453f; }
+
+// color/__init__.py:7-10
+MI_DEV float rgb_gray(float r, float g, float b) { return (r * 0.299f + g * 0.587f) + b * 0.114f; }
+
+// tonemap.py:12-17 with gamma == 1 (linear_func into the f32 temp): clamp((x-lo)*inv, 0, 1)
+MI_DEV float norm01(float x, float lo, float inv) { return fminf(fmaxf((x - lo) * inv, 0.f), 1.f); }
+
+// Running statistics of tonemap.py:78-103 / camera_isp.py:117-128.  min/max are taken on
+// max(gray, 1e-4) and the (monotone) log is applied once when the partials are combined.
+struct StatsAcc {
+  float gmin, gmax, slog, sgray, s0, s1, s2;
+  MI_DEV void init() {
+    gmin = __builtin_inff(); gmax = -__builtin_inff();
+    slog = sgray = s0 = s1 = s2 = 0.f;
+  }
+  MI_DEV void add(float t0, float t1, float t2) {
+    float g = rgb_gray(t0, t1, t2);
+    float gc = fmaxf(g, 1e-4f);
+    gmin = fminf(gmin, gc); gmax = fmaxf(gmax, gc);
+    slog += hw_log2(gc);           // sum of log2; scaled by ln2 when combined
+    sgray += g; s0 += t0; s1 += t1; s2 += t2;
+  }
+};
+
+struct ReinhardK {
+  float map_key, ei, mean3[3], la, ca;
+};
+
+// reinhard_func (tonemap.py:120-131) / camera_isp.py:200-210 on an already normalised pixel.
+MI_DEV void reinhard_px(const float (&t)[3], const ReinhardK& k, float (&out)[3]) {
+  const float g = rgb_gray(t[0], t[1], t[2]);
+  if (k.ca == 0.f) {
+    // color_adapt == 0: adapt_color == gray and mean3 is the same for the three channels,
+    // so the three channels share one pow.
+    const float am = k.mean3[0] + k.la * (g - k.mean3[0]);
+    const float ad = hw_pow(k.ei * am, k.map_key);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = t[c] * hw_rcp(ad + t[c]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float ac = g + k.ca * (t[c] - g);
+      const float am = k.mean3[c] + k.la * (ac - k.mean3[c]);
+      const float ad = hw_pow(k.ei * am, k.map_key);
+      out[c] = t[c] * hw_rcp(ad + t[c]);
+    }
+  }
+}
+
+// tonemap.py:12-17: clamp(((x-lo)*inv)^(1/gamma), 0, 1) * scale.  gamma_inv == 1 skips the pow
+// (powf(x, 1) == x exactly).  NaN -> 0 through fmaxf.
+MI_DEV float linear_px(float x, float lo, float inv, float gamma_inv, float scale) {
+  float v = (x - lo) * inv;
+  if (gamma_inv != 1.f) v = hw_pow(v, gamma_inv);
+  return fminf(fmaxf(v, 0.f), 1.f) * scale;
+}
+
+#pragma clang fp contract(off)

@@ -1,0 +1,470 @@
+// LDS-tiled Bayer demosaic (bayer.py:115-177 of the reference) with pluggable sources and
+// epilogues.  One 256-thread block (4 wave64) produces a 128x32-pixel output tile:
+//   1. fill : the CFA tile + 2-px halo is staged in LDS in the work type E (f16 or f32); packed
+//             12/16-bit sources are unpacked on the way (packed.py:24-44,149-157), 8 pixels
+//             (12 or 16 coalesced bytes) per lane;
+//   2. strip: every lane owns a 2-row x 8-col strip, reads its 6x12 window from LDS once
+//             (b32 + b128 + b32 per row) and evaluates the four 13-tap diamond kernels with
+//             compile-time weights, accumulating in fp32 in the reference's tap order;
+//   3. epilogue: store RGB (16-byte stores), or feed the tonemap reductions / final map of the
+//             fused config-2 pipeline without ever writing the intermediate RGB image.
+// Arithmetic contract: the demosaic is bit-exact against oracle/isp_oracle.py:bayer_to_rgb
+// (same operation order; products of <=16-bit inputs with the integer weights are exact in
+// fp32, so fmaf == mul+add for E = f16; E = f32 uses separate mul and add).
+#pragma once
+#include "isp_common.h"
+#include "isp_math.h"
+
+#pragma clang fp contract(off)
+
+#include <type_traits>
+
+namespace tile {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F> MI_DEV void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+constexpr int TILE_W = 128, TILE_H = 32;
+constexpr int STRIP_W = 8, STRIP_H = 2;
+constexpr int STRIPS_X = TILE_W / STRIP_W;            // 16 lanes across
+constexpr int LDS_COLS = TILE_W + 16;                 // image cols [c0-8, c0+TILE_W+8)
+constexpr int LDS_ROWS = TILE_H + 4;                  // image rows [r0-2, r0+TILE_H+2)
+constexpr int UNITS = LDS_COLS / 8;                   // 8-px load units per LDS row
+constexpr int THREADS = 256;
+
+template <class E> struct Pitch;                      // LDS row pitch in elements (16-B multiple)
+template <> struct Pitch<half_t> { static constexpr int value = LDS_COLS + 8; };
+template <> struct Pitch<float> { static constexpr int value = LDS_COLS + 4; };
+
+enum SrcKind { SRC_CFA_U8 = 0, SRC_CFA_U16 = 1, SRC_CFA_F16 = 2, SRC_CFA_F32 = 3,
+               SRC_PACKED12 = 4, SRC_PACKED12_IDS = 5, SRC_PACKED16 = 6 };
+enum Epi { EPI_STORE = 0, EPI_MINMAX = 1, EPI_STATS = 2, EPI_RH_MINMAX = 3, EPI_RH_STORE = 4 };
+
+struct Params {
+  const void* src;        // CFA image or packed bytes
+  void* dst;              // RGB output (EPI_STORE / EPI_RH_STORE)
+  const float* fp;        // FrameParams (device) for the tonemap epilogues
+  float* partials;        // per-block partials, SoA with stride part_stride
+  int part_stride;
+  int H, W;
+  int src_kind;
+  int src_fast;           // packed sources: rows are 4-byte (12-bit) / 16-byte (16-bit) aligned
+  int out_dtype;
+  int vec_store;          // dst rows allow 16-byte (8-byte for u8) vector stores
+  int has_ccm;
+  float ccm[9];
+  float in_scale;         // scale_factor of the CFA dtype (types.py:12-18)
+  float k_decode;         // f32(scale(E)/4095) or f32(scale(E)/65535) for packed sources
+  float out_scale;        // scale_factor of the output dtype
+  float gamma_inv, la, ca;
+};
+
+// 13-tap diamond, reference order (bayer.py:15-27): (d_row, d_col)
+__device__ constexpr int8_t TAP_DR[13] = {-2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2};
+__device__ constexpr int8_t TAP_DC[13] = {0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0};
+// weights [kernel][tap][channel] (bayer.py:30-55): K0 red site, K1 green (red above/below),
+// K2 green (red left/right), K3 blue site.  Every channel sums to 16.
+__device__ constexpr int8_t KW[4][13][3] = {
+    {{0, -2, -3}, {0, 0, 4}, {0, 4, 0}, {0, 0, 4}, {0, -2, -3}, {0, 4, 0}, {16, 8, 12},
+     {0, 4, 0}, {0, -2, -3}, {0, 0, 4}, {0, 4, 0}, {0, 0, 4}, {0, -2, -3}},
+    {{-2, 0, 1}, {-2, 0, -2}, {8, 0, 0}, {-2, 0, -2}, {1, 0, -2}, {0, 0, 8}, {10, 16, 10},
+     {0, 0, 8}, {1, 0, -2}, {-2, 0, -2}, {8, 0, 0}, {-2, 0, -2}, {-2, 0, 1}},
+    {{1, 0, -2}, {-2, 0, -2}, {0, 0, 8}, {-2, 0, -2}, {-2, 0, 1}, {8, 0, 0}, {10, 16, 10},
+     {8, 0, 0}, {-2, 0, 1}, {-2, 0, -2}, {0, 0, 8}, {-2, 0, -2}, {1, 0, -2}},
+    {{-3, -2, 0}, {4, 0, 0}, {0, 4, 0}, {4, 0, 0}, {-3, -2, 0}, {0, 4, 0}, {12, 8, 16},
+     {0, 4, 0}, {-3, -2, 0}, {4, 0, 0}, {0, 4, 0}, {4, 0, 0}, {-3, -2, 0}}};
+
+// ---------------------------------------------------------------------------------------------
+// unpack helpers
+// ---------------------------------------------------------------------------------------------
+// One 24-bit group w = b0 | b1<<8 | b2<<16 -> two 12-bit values.
+// standard (packed.py:24-31): p0 = (b1&0xF)<<8 | b0 = w & 0xFFF ; p1 = b2<<4 | b1>>4 = w >> 12
+// IDS      (packed.py:37-44): p0 = b0<<4 | (b2&0xF)           ; p1 = b1<<4 | b2>>4
+MI_DEV void unpack_pair(uint32_t w, bool ids, uint32_t& p0, uint32_t& p1) {
+  if (!ids) {
+    p0 = w & 0xFFFu;
+    p1 = (w >> 12) & 0xFFFu;
+  } else {
+    const uint32_t b0 = w & 0xFFu, b1 = (w >> 8) & 0xFFu, b2 = (w >> 16) & 0xFFu;
+    p0 = (b0 << 4) | (b2 & 0xFu);
+    p1 = (b1 << 4) | (b2 >> 4);
+  }
+}
+
+// 8 pixels from 12 packed bytes held in three little-endian dwords
+MI_DEV void unpack12x8(uint32_t d0, uint32_t d1, uint32_t d2, bool ids, uint32_t (&v)[8]) {
+  const uint32_t w0 = d0 & 0xFFFFFFu;
+  const uint32_t w1 = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
+  const uint32_t w2 = (d1 >> 16) | ((d2 & 0xFFu) << 16);
+  const uint32_t w3 = d2 >> 8;
+  unpack_pair(w0, ids, v[0], v[1]);
+  unpack_pair(w1, ids, v[2], v[3]);
+  unpack_pair(w2, ids, v[4], v[5]);
+  unpack_pair(w3, ids, v[6], v[7]);
+}
+
+// scaled write of packed.py:98-100: cast(f32(v) * f32(scale/4095), E)
+template <class E> MI_DEV E decode_scaled(uint32_t v, float k) { return (E)((float)v * k); }
+
+template <class E> MI_DEV void lds_store8(E* p, const E (&v)[8]);
+template <> MI_DEV void lds_store8<half_t>(half_t* p, const half_t (&v)[8]) {
+  typedef half_t h8 __attribute__((ext_vector_type(8)));
+  h8 x = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  *reinterpret_cast<h8*>(p) = x;
+}
+template <> MI_DEV void lds_store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 1: fill the LDS tile.  LDS (lr, lc) <-> image (rb + lr, cb + lc), rb = r0-2, cb = c0-8.
+// Out-of-image elements are zero (they contribute 0*w, an exact no-op, to the accumulators).
+// ---------------------------------------------------------------------------------------------
+template <class E>
+MI_DEV void fill_packed(const Params& p, E* lds, int rb, int cb) {
+  constexpr int PITCH = Pitch<E>::value;
+  const uint8_t* base = static_cast<const uint8_t*>(p.src);
+  const bool is16 = p.src_kind == SRC_PACKED16;
+  const bool ids = p.src_kind == SRC_PACKED12_IDS;
+  const size_t pitch = is16 ? (size_t)p.W * 2 : (size_t)p.W * 3 / 2;
+  for (int u = threadIdx.x; u < LDS_ROWS * UNITS; u += THREADS) {
+    const int lr = u / UNITS, lu = u - lr * UNITS;
+    const int r = rb + lr, c = cb + lu * 8;
+    E out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (E)0.f;
+    if (r >= 0 && r < p.H && c >= 0 && c < p.W) {
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0;
+      const uint8_t* rowp = base + (size_t)r * pitch;
+      const bool whole = c + 8 <= p.W;
+      if (!is16) {
+        const uint8_t* q = rowp + (size_t)c * 3 / 2;          // c % 8 == 0 -> 12-byte multiple
+        if (whole && p.src_fast) {
+          const uint32_t* q32 = reinterpret_cast<const uint32_t*>(q);
+          unpack12x8(q32[0], q32[1], q32[2], ids, v);
+        } else {
+          const int npair = whole ? 4 : (p.W - c) / 2;        // W is even
+          for (int j = 0; j < npair; ++j) {
+            const uint32_t w = q[3 * j] | (q[3 * j + 1] << 8) | (q[3 * j + 2] << 16);
+            unpack_pair(w, ids, v[2 * j], v[2 * j + 1]);
+          }
+        }
+      } else {
+        const uint8_t* q = rowp + (size_t)c * 2;
+        if (whole && p.src_fast) {
+          const uint4 d = *reinterpret_cast<const uint4*>(q);  // little-endian u16 pairs
+          v[0] = d.x & 0xFFFFu; v[1] = d.x >> 16; v[2] = d.y & 0xFFFFu; v[3] = d.y >> 16;
+          v[4] = d.z & 0xFFFFu; v[5] = d.z >> 16; v[6] = d.w & 0xFFFFu; v[7] = d.w >> 16;
+        } else {
+          const int n = whole ? 8 : p.W - c;
+          for (int j = 0; j < n; ++j) v[j] = q[2 * j] | (q[2 * j + 1] << 8);
+        }
+      }
+      const int n = whole ? 8 : p.W - c;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = i < n ? decode_scaled<E>(v[i], p.k_decode) : (E)0.f;
+    }
+    lds_store8<E>(lds + lr * PITCH + lu * 8, out);
+  }
+}
+
+template <class E, class S>
+MI_DEV void fill_plain(const Params& p, E* lds, int rb, int cb) {
+  constexpr int PITCH = Pitch<E>::value;
+  const S* src = static_cast<const S*>(p.src);
+  constexpr int NEED = TILE_W + 4;                     // image cols [c0-2, c0+TILE_W+2)
+  for (int i = threadIdx.x; i < LDS_ROWS * NEED; i += THREADS) {
+    const int lr = i / NEED, k = i - lr * NEED;
+    const int lc = k + 6;                              // c0-2 == cb+6
+    const int r = rb + lr, c = cb + lc;
+    float v = 0.f;
+    if (r >= 0 && r < p.H && c >= 0 && c < p.W) v = (float)src[(size_t)r * p.W + c];
+    lds[lr * PITCH + lc] = (E)v;
+  }
+}
+
+template <class E> MI_DEV void fill_tile(const Params& p, E* lds, int rb, int cb);
+template <> MI_DEV void fill_tile<half_t>(const Params& p, half_t* lds, int rb, int cb) {
+  switch (p.src_kind) {
+    case SRC_CFA_U8: fill_plain<half_t, uint8_t>(p, lds, rb, cb); break;   // 0..255 exact in f16
+    case SRC_CFA_F16: fill_plain<half_t, half_t>(p, lds, rb, cb); break;
+    default: fill_packed<half_t>(p, lds, rb, cb); break;
+  }
+}
+template <> MI_DEV void fill_tile<float>(const Params& p, float* lds, int rb, int cb) {
+  switch (p.src_kind) {
+    case SRC_CFA_U16: fill_plain<float, uint16_t>(p, lds, rb, cb); break;
+    case SRC_CFA_F32: fill_plain<float, float>(p, lds, rb, cb); break;
+    case SRC_CFA_U8: fill_plain<float, uint8_t>(p, lds, rb, cb); break;
+    case SRC_CFA_F16: fill_plain<float, half_t>(p, lds, rb, cb); break;
+    default: fill_packed<float>(p, lds, rb, cb); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 2: the lane's 6 x 12 window, LDS -> registers
+// ---------------------------------------------------------------------------------------------
+template <class E> MI_DEV void load_window(const E* lds, int tx, int ty, float (&win)[6][12]);
+template <> MI_DEV void load_window<half_t>(const half_t* lds, int tx, int ty, float (&win)[6][12]) {
+  constexpr int PITCH = Pitch<half_t>::value;
+  typedef half_t h2 __attribute__((ext_vector_type(2)));
+  typedef half_t h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const half_t* rp = lds + (2 * ty + k) * PITCH + 8 * tx + 6;
+    const h2 a = *reinterpret_cast<const h2*>(rp);
+    const h8 b = *reinterpret_cast<const h8*>(rp + 2);
+    const h2 c = *reinterpret_cast<const h2*>(rp + 10);
+    win[k][0] = (float)a[0]; win[k][1] = (float)a[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) win[k][2 + j] = (float)b[j];
+    win[k][10] = (float)c[0]; win[k][11] = (float)c[1];
+  }
+}
+template <> MI_DEV void load_window<float>(const float* lds, int tx, int ty, float (&win)[6][12]) {
+  constexpr int PITCH = Pitch<float>::value;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float* rp = lds + (2 * ty + k) * PITCH + 8 * tx + 6;
+    const float2 a = *reinterpret_cast<const float2*>(rp);
+    const float4 b = *reinterpret_cast<const float4*>(rp + 2);
+    const float4 c = *reinterpret_cast<const float4*>(rp + 6);
+    const float2 d = *reinterpret_cast<const float2*>(rp + 10);
+    win[k][0] = a.x; win[k][1] = a.y;
+    win[k][2] = b.x; win[k][3] = b.y; win[k][4] = b.z; win[k][5] = b.w;
+    win[k][6] = c.x; win[k][7] = c.y; win[k][8] = c.z; win[k][9] = c.w;
+    win[k][10] = d.x; win[k][11] = d.y;
+  }
+}
+
+// filter_at (bayer.py:138-155) for the pixel at strip position (i, k): sequential fp32
+// accumulation over the non-zero taps in reference order.  EXACT: products are exact in fp32,
+// so a fused multiply-add gives the same bits as mul-then-add.
+template <int KIDX, bool EXACT, int I, int K>
+MI_DEV void accumulate(const float (&win)[6][12], float (&acc)[3]) {
+  acc[0] = acc[1] = acc[2] = 0.f;
+  static_for<0, 13>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const float x = win[I + 2 + TAP_DR[t]][K + 2 + TAP_DC[t]];
+    static_for<0, 3>([&](auto cc) {
+      constexpr int ch = decltype(cc)::value;
+      constexpr int w = KW[KIDX][t][ch];
+      if constexpr (w != 0) {
+        if constexpr (EXACT) acc[ch] = __builtin_fmaf(x, (float)w, acc[ch]);
+        else acc[ch] = acc[ch] + x * (float)w;
+      }
+    });
+  });
+}
+
+// in-bounds weight sums for a border pixel (the `t` of bayer.py:143-149)
+template <int KIDX>
+MI_DEV void border_weight(int r, int c, int H, int W, float (&t3)[3]) {
+  t3[0] = t3[1] = t3[2] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 13; ++t) {
+    const int rr = r + TAP_DR[t], cc = c + TAP_DC[t];
+    if (rr >= 0 && rr < H && cc >= 0 && cc < W) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) t3[ch] += (float)KW[KIDX][t][ch];
+    }
+  }
+}
+
+// One demosaiced pixel, normalised, colour-corrected and clamped to [0,1] (bayer.py:151-155).
+template <int KIDX, bool EXACT, int I, int K>
+MI_DEV void demosaic_px(const Params& p, const float (&win)[6][12], int r, int c, float (&rgb)[3]) {
+  float acc[3];
+  accumulate<KIDX, EXACT, I, K>(win, acc);
+  const bool interior = r >= 2 && r < p.H - 2 && c >= 2 && c < p.W - 2;
+  if (interior) {
+    if (p.in_scale == 1.f) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) acc[ch] *= 0.0625f;           // == / (1 * 16), exact
+    } else {
+      const float d = p.in_scale * 16.f;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] / d;        // correctly rounded division
+    }
+  } else {
+    float t3[3];
+    border_weight<KIDX>(r, c, p.H, p.W, t3);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] / (p.in_scale * t3[ch]);
+  }
+  if (p.has_ccm) {
+    const float a = acc[0], b = acc[1], d = acc[2];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      acc[ch] = (p.ccm[3 * ch] * a + p.ccm[3 * ch + 1] * b) + p.ccm[3 * ch + 2] * d;
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) rgb[ch] = fminf(fmaxf(acc[ch], 0.f), 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stores: one strip row = 8 px * 3 ch = 24 elements, contiguous in the (H, W, 3) output
+// ---------------------------------------------------------------------------------------------
+template <class T>
+MI_DEV void store_row(T* dst, const float (&v)[24], int npx, bool vec) {
+  T o[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) o[i] = cast_out<T>(v[i]);
+  if (vec && npx == 8) {
+    if (sizeof(T) == 1) {
+      const uint2* s = reinterpret_cast<const uint2*>(o);
+      uint2* d = reinterpret_cast<uint2*>(dst);
+      d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    } else {
+      constexpr int N = (int)(sizeof(T) * 24 / 16);
+      const uint4* s = reinterpret_cast<const uint4*>(o);
+      uint4* d = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+      for (int i = 0; i < N; ++i) d[i] = s[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 24; ++i)
+      if (i < npx * 3) dst[i] = o[i];      // static indices: keeps o[] in registers
+  }
+}
+
+MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], int npx) {
+  const size_t off = ((size_t)r * p.W + c) * 3;
+  switch (p.out_dtype) {
+    case MI_U8: store_row<uint8_t>(static_cast<uint8_t*>(p.dst) + off, v, npx, p.vec_store); break;
+    case MI_U16: store_row<uint16_t>(static_cast<uint16_t*>(p.dst) + off, v, npx, p.vec_store); break;
+    case MI_F16: store_row<half_t>(static_cast<half_t*>(p.dst) + off, v, npx, p.vec_store); break;
+    default: store_row<float>(static_cast<float*>(p.dst) + off, v, npx, p.vec_store); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel.  PR/PC: parity offsets of the CFA pattern relative to RGGB, so that the kernel used
+// at (row, col) is K[((row+PR)&1) + 2*((col+PC)&1)] (bayer.py:92-97,165-175):
+// RGGB (0,0), GBRG (1,0), GRBG (0,1), BGGR (1,1).
+// ---------------------------------------------------------------------------------------------
+template <class E, int PR, int PC, int EPI>
+__global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
+  constexpr int PITCH = Pitch<E>::value;
+  constexpr bool EXACT = sizeof(E) == 2;
+  __shared__ __attribute__((aligned(16))) E lds[LDS_ROWS * PITCH];
+  __shared__ float red[4][8];
+
+  const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
+  const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+  const int r0 = by * TILE_H, c0 = bx * TILE_W;
+
+  fill_tile<E>(p, lds, r0 - 2, c0 - 8);
+  __syncthreads();
+
+  const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
+  const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
+  const bool active = r < p.H && c < p.W;               // H, W even -> both rows, pixel pairs in
+  const int npx = active ? (p.W - c < 8 ? p.W - c : 8) : 0;
+
+  // tonemap scalars (uniform loads); unused ones are dead code per EPI
+  float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f;
+  ReinhardK rk;
+  if (EPI >= EPI_STATS) { lo = p.fp[FP_LO]; inv = p.fp[FP_INV]; }
+  if (EPI >= EPI_RH_MINMAX) {
+    rk.map_key = p.fp[FP_MAPKEY]; rk.ei = p.fp[FP_EI];
+    rk.mean3[0] = p.fp[FP_MEAN3]; rk.mean3[1] = p.fp[FP_MEAN3 + 1]; rk.mean3[2] = p.fp[FP_MEAN3 + 2];
+    rk.la = p.la; rk.ca = p.ca;
+  }
+  if (EPI == EPI_RH_STORE) { lo2 = p.fp[FP_LO2]; inv2 = p.fp[FP_INV2]; }
+
+  float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  StatsAcc st; st.init();
+
+  if (active) {
+    float win[6][12];
+    load_window<E>(lds, tx, ty, win);
+    static_for<0, 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      float row[24];
+      static_for<0, 8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        // kernel index is a compile-time function of the strip position and the pattern
+        constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
+        float rgb[3];
+        demosaic_px<KIDX, EXACT, i, k>(p, win, r + i, c + k, rgb);
+        if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) row[3 * k + ch] = rgb[ch] * p.out_scale;
+        } else {
+          // the reference materialises the demosaiced image in the work dtype (scale 1)
+          float x[3];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) x[ch] = (float)(E)rgb[ch];
+          const bool live = k < npx;
+          if constexpr (EPI == EPI_MINMAX) {
+            if (live) {
+              vmin = fminf(vmin, fminf(x[0], fminf(x[1], x[2])));
+              vmax = fmaxf(vmax, fmaxf(x[0], fmaxf(x[1], x[2])));
+            }
+          } else {
+            float t[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) t[ch] = norm01(x[ch], lo, inv);
+            if constexpr (EPI == EPI_STATS) {
+              if (live) st.add(t[0], t[1], t[2]);
+            } else {
+              float q[3];
+              reinhard_px(t, rk, q);
+              if constexpr (EPI == EPI_RH_MINMAX) {
+                if (live) {
+                  vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
+                  vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
+                }
+              } else {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                  row[3 * k + ch] = linear_px(q[ch], lo2, inv2, p.gamma_inv, p.out_scale);
+              }
+            }
+          }
+        }
+      });
+      if constexpr (EPI == EPI_STORE || EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
+    });
+  }
+
+  if (EPI == EPI_MINMAX || EPI == EPI_RH_MINMAX) {
+    const float v[2] = {vmin, vmax};
+    const int op[2] = {0, 1};
+    block_reduce_store<2>(v, op, red, p.partials, p.part_stride, blockIdx.x);
+  } else if (EPI == EPI_STATS) {
+    const float v[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
+    const int op[7] = {0, 1, 2, 2, 2, 2, 2};
+    block_reduce_store<7>(v, op, red, p.partials, p.part_stride, blockIdx.x);
+  }
+}
+
+// host-side launchers, one per pattern translation unit (isp_tile_p{0..3}.hip)
+int launch_rggb(const Params& p, int work_dtype, int epi, hipStream_t stream);
+int launch_grbg(const Params& p, int work_dtype, int epi, hipStream_t stream);
+int launch_gbrg(const Params& p, int work_dtype, int epi, hipStream_t stream);
+int launch_bggr(const Params& p, int work_dtype, int epi, hipStream_t stream);
+static inline int launch(const Params& p, int work_dtype, int pattern, int epi, hipStream_t stream) {
+  switch (pattern) {
+    case MI_RGGB: return launch_rggb(p, work_dtype, epi, stream);
+    case MI_GRBG: return launch_grbg(p, work_dtype, epi, stream);
+    case MI_GBRG: return launch_gbrg(p, work_dtype, epi, stream);
+    default: return launch_bggr(p, work_dtype, epi, stream);
+  }
+}
+
+static inline int num_tiles(int H, int W) {
+  return ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+}
+
+}  // namespace tile

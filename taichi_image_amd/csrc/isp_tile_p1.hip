@@ -1,0 +1,5 @@
+// Tile kernels for the GRBG pattern (BayerPattern value 1): parity offsets (PR, PC) = (0, 1).
+#define PAT_PR 0
+#define PAT_PC 1
+#define PAT_FN launch_grbg
+#include "isp_tile_inst.inc"

@@ -1,0 +1,5 @@
+// Tile kernels for the GBRG pattern (BayerPattern value 2): parity offsets (PR, PC) = (1, 0).
+#define PAT_PR 1
+#define PAT_PC 0
+#define PAT_FN launch_gbrg
+#include "isp_tile_inst.inc"

@@ -1,0 +1,78 @@
+"""Fused stateless chain of the reference's test/pipeline.py:26-32 (BASELINE config 2):
+
+    decode12(packed, dtype=work, scaled=True) -> bayer_to_rgb -> tonemap_reinhard(dtype=out)
+
+as four tile passes over the packed frame (csrc/isp_api.hip: pipeline_frame).  Results are
+identical to calling packed.decode12 / bayer.bayer_to_rgb / tonemap.tonemap_reinhard in turn.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native, types
+from .bayer import BayerPattern
+
+
+def _check_packed(packed):
+    if not isinstance(packed, torch.Tensor):
+        raise TypeError("packed frame must be a torch.Tensor")
+    assert packed.ndim == 2 and packed.dtype == torch.uint8, "packed frame must be (H, W*3/2) uint8"
+    assert packed.is_cuda and packed.is_contiguous(), "packed frame must be a contiguous device tensor"
+    assert packed.shape[1] % 3 == 0, "packed-12 rows must hold whole pixel pairs"
+    H, W = packed.shape[0], packed.shape[1] * 2 // 3
+    assert H % 2 == 0 and W % 2 == 0, "image must be even size"
+    return H, W
+
+
+def pipeline12_reinhard(packed, pattern=BayerPattern.RGGB, ids_format=False, correct_colors=None,
+                        work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0, light_adapt=1.0,
+                        color_adapt=0.0, out=None):
+    H, W = _check_packed(packed)
+    work, odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
+    if out is None:
+        out = torch.empty((H, W, 3), dtype=odt.torch, device=packed.device)
+    ws = _native.workspace(H, W, packed.device)
+    _native.check(_native.lib().mi_isp_pipeline12_reinhard(
+        packed.data_ptr(), out.data_ptr(), H, W, int(bool(ids_format)), pattern.value, _native.ccm_arg(correct_colors),
+        work.code, odt.code, float(gamma), float(intensity), float(light_adapt), float(color_adapt), ws.data_ptr(),
+        _native.stream_ptr(packed.device)))
+    return out
+
+
+class BatchPipeline:
+    """Independent frames, one frame per HIP stream in flight (BASELINE config 4 on one GPU).
+
+    Owns `n_streams` streams, the per-frame workspaces and the output tensors so that a step is
+    one C call issuing 7 launches per frame with no allocation on the way."""
+
+    def __init__(self, n_frames, H, W, device, n_streams=4, pattern=BayerPattern.RGGB, ids_format=False,
+                 correct_colors=None, work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0,
+                 light_adapt=1.0, color_adapt=0.0):
+        self.n_frames, self.H, self.W, self.device = n_frames, H, W, device
+        self.work, self.odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
+        self.pattern, self.ids = pattern, int(bool(ids_format))
+        self.ccm = _native.ccm_arg(correct_colors)
+        self.params = (float(gamma), float(intensity), float(light_adapt), float(color_adapt))
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
+        self.stream_ptrs = (_native.c_void_p * len(self.streams))(*[s.cuda_stream for s in self.streams])
+        ws_bytes = int(_native.lib().mi_isp_workspace_bytes(H, W))
+        self.ws = torch.empty(ws_bytes * n_frames, dtype=torch.uint8, device=device)
+        self.outputs = [torch.empty((H, W, 3), dtype=self.odt.torch, device=device) for _ in range(n_frames)]
+        self.out_ptrs = _native.ptr_array(self.outputs)
+
+    def __call__(self, frames):
+        assert len(frames) == self.n_frames
+        for f in frames:
+            assert _check_packed(f) == (self.H, self.W)
+        # the frames were produced on the current stream: make the worker streams wait for it
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+        in_ptrs = _native.ptr_array(frames)
+        g, i, la, ca = self.params
+        _native.check(_native.lib().mi_isp_pipeline12_reinhard_batch(
+            in_ptrs, self.out_ptrs, self.n_frames, self.H, self.W, self.ids, self.pattern.value, self.ccm,
+            self.work.code, self.odt.code, g, i, la, ca, self.ws.data_ptr(), self.stream_ptrs, len(self.streams)))
+        for s in self.streams:
+            cur.wait_stream(s)
+        return self.outputs

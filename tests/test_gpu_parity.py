@@ -1,0 +1,399 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the Python call surface that mirrors the
+reference) against the CPU oracle on the same seeded inputs.
+
+Contract (BASELINE.json north_star): bit-exact for unpack / integer indexing -- and, because the
+kernels keep the reference's operation order, also for demosaic and bilinear resize; within
+1e-4 relative (+1 unit of the output type) for the transcendental tonemap stages.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import isp_oracle as O
+from tests.util import assert_close, assert_exact, natural_packed12, random_cfa
+
+pytestmark = pytest.mark.gpu
+
+DT = ["u8", "u16", "f16", "f32"]
+
+
+@pytest.fixture(scope="module")
+def ti():
+    import taichi_image_amd as t
+    return t
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def tok(ti, name):
+    return getattr(ti.types, name)
+
+
+def pat(ti, p):
+    return ti.BayerPattern(p)
+
+
+# ---------------------------------------------------------------------------------------------
+# packed.py
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ids", [False, True])
+@pytest.mark.parametrize("dtype,scaled", [("u16", False), ("u16", True), ("f16", True), ("f32", True), ("f16", False),
+                                          ("u8", True)])
+@pytest.mark.parametrize("n_pairs", [0, 1, 3, 4, 37, 4096 + 5])
+def test_decode12(ti, rng, ids, dtype, scaled, n_pairs):
+    enc = rng.integers(0, 256, n_pairs * 3).astype(np.uint8)
+    ref = O.decode12(enc, dtype, scaled, ids)
+    got = ti.packed.decode12(enc, tok(ti, dtype), scaled=scaled, ids_format=ids)
+    assert_exact(got, ref, f"decode12 {dtype} scaled={scaled} ids={ids}")
+
+
+def test_decode12_kat(ti):
+    """Hand-derived from packed.py:24-31,37-44."""
+    enc = np.array([0xAB, 0xCD, 0xEF], np.uint8)
+    assert ti.packed.decode12(enc).tolist() == [0xDAB, 0xEFC]
+    assert ti.packed.decode12(enc, ids_format=True).tolist() == [0xABF, 0xCDE]
+    v = np.array([0, 1, 2047, 2048, 3499, 3836, 4095, 0], np.uint16)
+    d = ti.packed.decode12(ti.packed.encode12(v), ti.types.f16, scaled=True)
+    assert d.view(np.uint16).tolist() == [0x0000, 0x0C00, 0x3800, 0x3800, 0x3AD6, 0x3B7E, 0x3C00, 0x0000]
+    assert ti.packed.decode16(np.array([0x34, 0x12], np.uint8)).tolist() == [0x1234]
+
+
+def test_decode12_shapes_and_unaligned(ti, rng, dev):
+    enc = rng.integers(0, 256, (6, 5, 24)).astype(np.uint8)
+    assert_exact(ti.packed.decode12(enc, ti.types.f32, scaled=True), O.decode12(enc, "f32", True))
+    # a device view that is not 4-byte aligned exercises the byte path
+    buf = torch.from_numpy(rng.integers(0, 256, 3 * 1001 + 1).astype(np.uint8)).to(dev)
+    view = buf[1:]
+    got = ti.packed.decode12(view, ti.types.u16)
+    assert got.device == view.device and got.dtype == torch.uint16
+    assert_exact(got.cpu().numpy(), O.decode12(buf.cpu().numpy()[1:], "u16"))
+
+
+def test_encode_decode_roundtrip(ti, rng):
+    """The reference's only assertion (test/packed.py:6-15), plus the scaled variants."""
+    for _ in range(20):
+        size = int(rng.integers(0, 1000)) * 2
+        x = rng.integers(0, 2 ** 12, size=size).astype(np.uint16)
+        assert np.all(ti.packed.decode12(ti.packed.encode12(x)) == x)
+    x = rng.integers(0, 2 ** 12, size=(64, 258)).astype(np.uint16)
+    for ids in (False, True):
+        assert_exact(ti.packed.encode12(x, ids_format=ids), O.encode12(x, ids_format=ids))
+    xf = rng.random((32, 64), dtype=np.float32)
+    for dt in ("f32", "f16"):
+        xs = xf.astype(O.NP_DTYPE[dt])
+        assert_exact(ti.packed.encode12(xs, scaled=True), O.encode12(xs, scaled=True), f"encode12 scaled {dt}")
+    x16 = rng.integers(0, 65536, size=(8, 32)).astype(np.uint16)
+    assert_exact(ti.packed.encode12(x16, scaled=True), O.encode12(x16, scaled=True), "encode12 scaled u16")
+
+
+def test_ids_layout_is_not_self_inverse(ti, rng):
+    """Reference quirk reproduced: packed.py:48-55 puts p0's low nibble in the HIGH nibble of byte 2,
+    packed.py:37-44 reads it from the LOW nibble, so IDS encode->decode swaps the low nibbles."""
+    x = rng.integers(0, 4096, 64).astype(np.uint16)
+    d = ti.packed.decode12(ti.packed.encode12(x, ids_format=True), ids_format=True)
+    p0, p1 = x[0::2], x[1::2]
+    assert np.array_equal(d[0::2], (p0 & 0xFF0) | (p1 & 0xF))
+    assert np.array_equal(d[1::2], (p1 & 0xFF0) | (p0 & 0xF))
+
+
+@pytest.mark.parametrize("dtype,scaled", [("u16", False), ("f16", True), ("f32", True), ("u8", True)])
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 1000 + 3])
+def test_decode16(ti, rng, dtype, scaled, n):
+    enc = rng.integers(0, 256, n * 2).astype(np.uint8)
+    assert_exact(ti.packed.decode16(enc, tok(ti, dtype), scaled=scaled), O.decode16(enc, dtype, scaled))
+
+
+# ---------------------------------------------------------------------------------------------
+# bayer.py
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("p", [0, 1, 2, 3])
+def test_rgb_to_bayer(ti, rng, p):
+    img = rng.random((10, 14, 3), dtype=np.float32)
+    assert_exact(ti.bayer.rgb_to_bayer(img, pat(ti, p)), O.rgb_to_bayer(img, p))
+    img8 = rng.integers(0, 256, (4, 6, 3)).astype(np.uint8)
+    assert_exact(ti.bayer.rgb_to_bayer(img8, pat(ti, p)), O.rgb_to_bayer(img8, p))
+
+
+@pytest.mark.parametrize("p", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 2), (4, 6), (34, 130), (66, 264), (64, 256)])
+def test_demosaic_bit_exact(ti, rng, p, dtype, shape):
+    cfa = random_cfa(rng, *shape, dtype)
+    got = ti.bayer.bayer_to_rgb(cfa, pat(ti, p))
+    assert_exact(got, O.bayer_to_rgb(cfa, p), f"demosaic {dtype} pattern {p} {shape}")
+
+
+@pytest.mark.parametrize("din,dout", [("f16", "f32"), ("f32", "f16"), ("u16", "f16"), ("u8", "f32"), ("f16", "u8"),
+                                      ("u16", "u8"), ("f32", "u16"), ("u8", "u16")])
+def test_demosaic_cross_dtype_and_ccm(ti, rng, din, dout):
+    cfa = random_cfa(rng, 70, 150, din)
+    assert_exact(ti.bayer.bayer_to_rgb(cfa, dtype=tok(ti, dout)), O.bayer_to_rgb(cfa, dtype=dout))
+    ccm = O.isp_color_matrix(True, O.DEFAULT_WB, O.DEFAULT_CC)
+    got = ti.bayer.bayer_to_rgb(cfa, pat(ti, 2), correct_colors=ccm, dtype=tok(ti, dout))
+    assert_exact(got, O.bayer_to_rgb(cfa, 2, ccm, dout), f"ccm {din}->{dout}")
+
+
+def test_demosaic_config1_full(ti):
+    """BASELINE config 1: 1920x1080 RGGB 16-bit frame, seed 1."""
+    cfa = np.random.default_rng(1).integers(0, 65536, (1080, 1920)).astype(np.uint16)
+    got = ti.bayer.bayer_to_rgb(cfa)
+    assert got.dtype == np.uint16 and got.shape == (1080, 1920, 3)
+    assert_exact(got, O.bayer_to_rgb(cfa), "config 1")
+
+
+def test_demosaic_constant_invariance_full_size(ti, dev):
+    """Every kernel's channel weights sum to 16 (also over the in-bounds taps at the borders),
+    so a constant CFA demosaics to the same constant everywhere -- checked at 4096x3072."""
+    for dt, val in ((torch.float16, 0.37), (torch.float32, 0.6180339)):
+        cfa = torch.full((3072, 4096), val, dtype=dt, device=dev)
+        rgb = ti.bayer.bayer_to_rgb(cfa)
+        assert rgb.shape == (3072, 4096, 3)
+        assert bool((rgb == cfa[0, 0]).all())
+
+
+def test_demosaic_torch_container(ti, rng, dev):
+    cfa = torch.from_numpy(random_cfa(rng, 32, 64, "f16")).to(dev)
+    out = ti.bayer.bayer_to_rgb(cfa)
+    assert isinstance(out, torch.Tensor) and out.device == cfa.device and out.dtype == torch.float16
+    assert_exact(out.cpu().numpy(), O.bayer_to_rgb(cfa.cpu().numpy()))
+    cpu = torch.from_numpy(random_cfa(rng, 8, 8, "f32"))
+    assert ti.bayer.bayer_to_rgb(cpu).device.type == "cpu"
+
+
+def test_demosaic_errors(ti, rng):
+    with pytest.raises(AssertionError):
+        ti.bayer.bayer_to_rgb(random_cfa(rng, 5, 8, "f32"))
+    with pytest.raises(AssertionError):
+        ti.bayer.bayer_to_rgb(rng.random((4, 4, 3), dtype=np.float32))
+    with pytest.raises(KeyError):
+        ti.bayer.bayer_to_rgb(np.zeros((4, 4), np.float64))
+    with pytest.raises(ValueError):
+        ti.bayer.bayer_to_rgb([[0, 1], [1, 0]])
+
+
+# ---------------------------------------------------------------------------------------------
+# interpolate.py
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f16", "f32", "u8"])
+@pytest.mark.parametrize("scale", [0.46875, 0.8, 1.0, 1.7, (0.3515625, 0.46875)])
+def test_resize_bilinear_bit_exact(ti, rng, dtype, scale):
+    src = rng.random((61, 83, 3), dtype=np.float32)
+    src = (src * 255).astype(np.uint8) if dtype == "u8" else src.astype(O.NP_DTYPE[dtype])
+    s = scale if isinstance(scale, tuple) else (scale, scale)
+    size = (int(83 * s[1]), int(61 * s[0]))
+    assert_exact(ti.interpolate.resize_bilinear(src, size, scale), O.resize_bilinear(src, size, scale),
+                 f"resize {dtype} {scale}")
+
+
+def test_resize_helpers_and_quirk(ti, rng):
+    src = rng.random((48, 64, 3), dtype=np.float32)
+    assert_exact(ti.interpolate.resize_width(src, 40), O.resize_bilinear(src, (40, int(48 * (40 / 64))), 40 / 64))
+    assert_exact(ti.interpolate.scale_bilinear(src, 0.8), O.resize_bilinear(src, (51, 38), 0.8))
+    # scale=None: the reference divides (w, h) by (H, W) -- axes crossed (interpolate.py:132-133)
+    assert_exact(ti.interpolate.resize_bilinear(src, (32, 24)), O.resize_bilinear(src, (32, 24), None))
+    out = ti.interpolate.resize_bilinear(src.astype(np.float16), (32, 24), 0.5, dtype=ti.types.f32)
+    assert_exact(out, O.resize_bilinear(src.astype(np.float16), (32, 24), 0.5, "f32"))
+
+
+@pytest.mark.parametrize("name", O.TRANSFORMS)
+def test_transform(ti, rng, name):
+    t = ti.ImageTransform(name)
+    shape = (9, 9, 3) if name == "transverse" else (7, 12, 3)
+    for dt in ("u8", "f16", "f32"):
+        src = (rng.random(shape) * 255).astype(O.NP_DTYPE[dt])
+        assert_exact(ti.interpolate.transform(src, t), O.transform(src, name), f"transform {name} {dt}")
+
+
+def test_transform_group_identities(ti, rng):
+    T = ti.ImageTransform
+    x = (rng.random((6, 10, 3)) * 255).astype(np.uint8)
+    tr = ti.interpolate.transform
+    assert np.array_equal(tr(tr(x, T.rotate_90), T.rotate_270), x)
+    assert np.array_equal(tr(tr(x, T.rotate_180), T.rotate_180), x)
+    assert np.array_equal(tr(tr(x, T.transpose), T.transpose), x)
+    assert np.array_equal(tr(tr(x, T.flip_horiz), T.flip_vert), tr(x, T.rotate_180))
+    with pytest.raises(AssertionError):
+        tr(x, T.transverse)
+
+
+# ---------------------------------------------------------------------------------------------
+# tonemap.py (stateless)
+# ---------------------------------------------------------------------------------------------
+def _rgb_image(rng, H, W, dtype):
+    packed = natural_packed12(rng, H, W)
+    return O.bayer_to_rgb(O.decode12(packed, dtype, scaled=True))
+
+
+@pytest.mark.parametrize("din", ["f16", "f32", "u8"])
+@pytest.mark.parametrize("dout", ["u8", "f16", "f32"])
+@pytest.mark.parametrize("gamma", [1.0, 0.6])
+def test_tonemap_linear(ti, rng, din, dout, gamma):
+    img = _rgb_image(rng, 50, 70, "f32")
+    img = (img * 255).astype(np.uint8) if din == "u8" else img.astype(O.NP_DTYPE[din])
+    got = ti.tonemap.tonemap_linear(img, gamma=gamma, dtype=tok(ti, dout))
+    assert_close(got, O.tonemap_linear(img, gamma, dout), f"tonemap_linear {din}->{dout}")
+
+
+@pytest.mark.parametrize("din,dout", [("f16", "u8"), ("f16", "f16"), ("f32", "f32"), ("f32", "u8"), ("u8", "u8")])
+@pytest.mark.parametrize("params", [dict(), dict(gamma=0.6), dict(gamma=2.2, intensity=0.5, light_adapt=0.8, color_adapt=0.3)])
+def test_tonemap_reinhard(ti, rng, din, dout, params):
+    img = _rgb_image(rng, 66, 94, "f32")
+    img = (img * 255).astype(np.uint8) if din == "u8" else img.astype(O.NP_DTYPE[din])
+    got = ti.tonemap.tonemap_reinhard(img, dtype=tok(ti, dout), **params)
+    assert_close(got, O.tonemap_reinhard(img, dtype=dout, **params), f"tonemap_reinhard {din}->{dout} {params}")
+
+
+def test_tonemap_reinhard_black_pixels(ti, rng):
+    """All-black pixels give 0 * inf = NaN inside the reference formula (light_adapt = 1); the
+    library defines NaN -> 0 at the output cast and ignores NaN in the reductions."""
+    img = _rgb_image(rng, 32, 48, "f32")
+    img[3:9, 5:20] = 0.0
+    for dout in ("u8", "f16"):
+        got = ti.tonemap.tonemap_reinhard(img, dtype=tok(ti, dout))
+        ref = O.tonemap_reinhard(img, dtype=dout)
+        assert_close(got, ref, f"black {dout}")
+        assert np.all(got[3:9, 5:20] == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused config-2 pipeline (test/pipeline.py:26-32 of the reference)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("p,ids", [(0, False), (1, False), (2, True), (3, False)])
+@pytest.mark.parametrize("work,dout", [("f16", "f16"), ("f16", "u8"), ("f32", "f32")])
+@pytest.mark.parametrize("shape", [(64, 256), (70, 200), (34, 136)])
+def test_pipeline12_reinhard(ti, rng, dev, p, ids, work, dout, shape):
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    packed = natural_packed12(rng, *shape, pattern=p, ids_format=ids)
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), pat(ti, p), ids, work_dtype=tok(ti, work),
+                              dtype=tok(ti, dout)).cpu().numpy()
+    ref = O.pipeline12_reinhard(packed, p, ids, None, work, dout)
+    assert_close(got, ref, f"pipeline12 {shape} p{p} {work}->{dout}")
+
+
+def test_pipeline12_params_and_ccm(ti, rng, dev):
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    packed = natural_packed12(rng, 96, 160)
+    ccm = O.isp_color_matrix(True, O.DEFAULT_WB, O.DEFAULT_CC)
+    kw = dict(gamma=0.6, intensity=1.5, light_adapt=0.7, color_adapt=0.4)
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), correct_colors=ccm, **kw).cpu().numpy()
+    ref = O.pipeline12_reinhard(packed, correct_colors=ccm, **kw)
+    assert_close(got, ref, "pipeline12 ccm+params")
+
+
+def test_pipeline12_matches_unfused_chain_4k(ti, dev):
+    """Full BASELINE size: the fused four-pass pipeline against the unfused GPU chain
+    decode12 -> bayer_to_rgb -> tonemap_reinhard (each parity-tested against the oracle above),
+    and the demosaic stage against the oracle at full size."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    from taichi_image_amd.synthetic import synthetic_packed12
+    packed = synthetic_packed12(0)
+    pk = torch.from_numpy(packed).to(dev)
+    fused = pipeline12_reinhard(pk)
+    cfa = ti.packed.decode12(pk, ti.types.f16, scaled=True)
+    rgb = ti.bayer.bayer_to_rgb(cfa)
+    unfused = ti.tonemap.tonemap_reinhard(rgb, dtype=ti.types.f16)
+    assert fused.shape == (3072, 4096, 3) and fused.dtype == torch.float16
+    assert_close(fused.cpu().numpy(), unfused.cpu().numpy(), "fused vs unfused 4K")
+    ref_cfa = O.decode12(packed, "f16", scaled=True)
+    assert_exact(cfa.cpu().numpy(), ref_cfa, "decode12 4K")
+    assert_exact(rgb.cpu().numpy(), O.bayer_to_rgb(ref_cfa), "demosaic 4K")
+    # range property of the stateless Reinhard output: normalised to exactly [0, 1]
+    assert float(fused.float().min()) == 0.0 and float(fused.float().max()) == 1.0
+
+
+def test_batch_pipeline_equals_single(ti, rng, dev):
+    from taichi_image_amd.pipeline import BatchPipeline, pipeline12_reinhard
+    H, W = 64, 128
+    frames = [torch.from_numpy(natural_packed12(rng, H, W)).to(dev) for _ in range(5)]
+    bp = BatchPipeline(5, H, W, dev, n_streams=3)
+    outs = [o.clone() for o in bp(frames)]
+    torch.cuda.synchronize()
+    for f, o in zip(frames, outs):
+        assert torch.equal(o, pipeline12_reinhard(f))
+
+
+# ---------------------------------------------------------------------------------------------
+# camera_isp.py (stateful ISP)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cam,work", [("Camera16", "f16"), ("Camera32", "f32")])
+@pytest.mark.parametrize("kw", [dict(), dict(resize_width=96), dict(scale=0.5), dict(correct_colors=True, resize_width=80)])
+def test_isp_load_packed12_bit_exact(ti, rng, dev, cam, work, kw):
+    packed = natural_packed12(rng, 98, 168)
+    isp = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, **kw)
+    got = isp.load_packed12(torch.from_numpy(packed).to(dev))
+    ccm = O.isp_color_matrix(kw.get("correct_colors", False), O.DEFAULT_WB, O.DEFAULT_CC)
+    ref = O.isp_load_packed12(packed, work, correct_colors=ccm, resize_width=kw.get("resize_width", 0),
+                              scale=kw.get("scale"))
+    assert_exact(got.cpu().numpy(), ref, f"{cam}.load_packed12 {kw}")
+
+
+def test_isp_other_loaders(ti, rng, dev):
+    isp = ti.Camera16(ti.BayerPattern.GBRG, device=dev, resize_width=40)
+    raw16 = rng.integers(0, 65536, (48, 64)).astype(np.uint16)
+    enc = raw16.view(np.uint8).reshape(48, 128)
+    ref = O.isp_load_packed16(enc, "f16", O.GBRG, resize_width=40)
+    assert_exact(isp.load_packed16(torch.from_numpy(enc).to(dev)).cpu().numpy(), ref, "load_packed16")
+    sz, s = O.isp_output_size(48, 64, 40)
+    for name, fn in (("load_16u", O.load_16u), ("load_16f", O.load_16f)):
+        src = raw16 if name == "load_16u" else rng.integers(0, 2, (48, 64)).astype(np.uint16)
+        want = O.resize_bilinear(O.bayer_to_rgb(fn(src, "f16"), O.GBRG), sz, s)
+        assert_exact(getattr(isp, name)(torch.from_numpy(src).to(dev)).cpu().numpy(), want, name)
+    f = rng.random((48, 64), dtype=np.float32)
+    want = O.resize_bilinear(O.bayer_to_rgb(O.load_32f(f, "f16"), O.GBRG), sz, s)
+    assert_exact(isp.load_32f(torch.from_numpy(f).to(dev)).cpu().numpy(), want, "load_32f")
+    ids = natural_packed12(rng, 48, 64, O.GBRG, ids_format=True)
+    assert_exact(isp.load_packed12(torch.from_numpy(ids).to(dev), ids_format=True).cpu().numpy(),
+                 O.isp_load_packed12(ids, "f16", O.GBRG, True, resize_width=40), "load_packed12 ids")
+
+
+@pytest.mark.parametrize("cam,work", [("Camera16", "f16"), ("Camera32", "f32")])
+def test_isp_tonemap_reinhard_sequence(ti, rng, dev, cam, work):
+    """test/camera_isp.py:29-39 call sequence over three steps so the moving average is exercised."""
+    isp = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.3, resize_width=64, device=dev)
+    st = O.IspState(0.3)
+    for step in range(3):
+        packs = [natural_packed12(rng, 80, 128, dark=0.05 * step) for _ in range(3)]
+        imgs = [isp.load_packed12(torch.from_numpy(p).to(dev)) for p in packs]
+        refs = [O.isp_load_packed12(p, work, resize_width=64) for p in packs]
+        outs = isp.tonemap_reinhard(imgs, gamma=0.6)
+        m = st.update_metering(refs)
+        assert_close(isp.metrics.cpu().numpy(), m, f"metrics step {step}", rel=2e-5)
+        for k, (o, im, r) in enumerate(zip(outs, imgs, refs)):
+            ref_u8, ref_after = O.reinhard_isp(r, m, gamma=0.6)
+            assert_close(o.cpu().numpy(), ref_u8, f"u8 step {step} img {k}")
+            assert_close(im.cpu().numpy(), ref_after, f"in-place p step {step} img {k}")
+
+
+def test_isp_tonemap_linear_and_transforms(ti, rng, dev):
+    packs = [natural_packed12(rng, 64, 64) for _ in range(2)]
+    for name in O.TRANSFORMS:
+        isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=1.0, device=dev, transform=ti.ImageTransform(name))
+        imgs = [isp.load_packed12(torch.from_numpy(p).to(dev)) for p in packs]
+        refs = [O.isp_load_packed12(p, "f16") for p in packs]
+        m = O.IspState(1.0).update_metering(refs)
+        lin = isp.tonemap_linear([im.clone() for im in imgs], gamma=0.8)
+        for o, r in zip(lin, refs):
+            assert_close(o.cpu().numpy(), O.transform(O.linear_isp(r, m, 0.8), name), f"linear {name}")
+        isp.metrics = None
+        rh = isp.tonemap_reinhard(imgs, gamma=1.0, intensity=0.7, light_adapt=0.9, color_adapt=0.2)
+        for o, r in zip(rh, refs):
+            ref_u8, _ = O.reinhard_isp(r, m, 1.0, 0.7, 0.9, 0.2)
+            assert_close(o.cpu().numpy(), O.transform(ref_u8, name), f"reinhard {name}")
+
+
+def test_isp_constructor_and_set(ti, dev):
+    with pytest.raises(AssertionError):
+        ti.Camera16(ti.BayerPattern.RGGB, scale=0.5, resize_width=100, device=dev)
+    with pytest.raises(TypeError):
+        ti.Camera16("RGGB", device=dev)
+    isp = ti.Camera16(ti.BayerPattern.RGGB, resize_width=100, device=dev)
+    isp.set(scale=0.5)
+    assert isp.scale == 0.5 and isp.resize_width == 0
+    isp.set(resize_width=50)
+    assert isp.scale is None and isp.resize_width == 50
+    with pytest.raises(TypeError):
+        isp.tonemap_reinhard([], gamma=1)
+    assert ti.Camera16.__qualname__ == "Camera16" and callable(ti.Camera16.reinhard_kernel)
