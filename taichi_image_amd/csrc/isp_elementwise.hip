@@ -661,10 +661,10 @@ using namespace ew;
 
 extern "C" int mi_isp_decode12(const uint8_t* enc, void* out, int64_t n_px, int out_dtype, int scaled,
                                int ids_format, void* stream) {
-  MI_REQUIRE(enc && out, "decode12: null pointer");
   MI_REQUIRE(n_px >= 0 && n_px % 2 == 0, "decode12: pixel count must be even, got %lld", (long long)n_px);
   MI_REQUIRE(mi_valid_dtype(out_dtype), "decode12: bad dtype %d", out_dtype);
   if (n_px == 0) return 0;
+  MI_REQUIRE(enc && out, "decode12: null pointer");
   const float k = (float)((double)mi_scale_factor(out_dtype) / 4095.0);
   const int fast = mi_aligned(enc, 4) && mi_aligned(out, 16);
   const int64_t n_pairs = n_px / 2;
@@ -680,10 +680,10 @@ extern "C" int mi_isp_decode12(const uint8_t* enc, void* out, int64_t n_px, int 
 
 extern "C" int mi_isp_decode16(const uint8_t* enc, void* out, int64_t n_px, int out_dtype, int scaled,
                                void* stream) {
-  MI_REQUIRE(enc && out, "decode16: null pointer");
   MI_REQUIRE(n_px >= 0, "decode16: negative count");
   MI_REQUIRE(mi_valid_dtype(out_dtype), "decode16: bad dtype %d", out_dtype);
   if (n_px == 0) return 0;
+  MI_REQUIRE(enc && out, "decode16: null pointer");
   const float k = (float)((double)mi_scale_factor(out_dtype) / 65535.0);
   const int fast = mi_aligned(enc, 16) && mi_aligned(out, 16);
   hipStream_t s = (hipStream_t)stream;
@@ -698,10 +698,10 @@ extern "C" int mi_isp_decode16(const uint8_t* enc, void* out, int64_t n_px, int 
 
 extern "C" int mi_isp_encode12(const void* values, uint8_t* enc, int64_t n_px, int in_dtype, int scaled,
                                int ids_format, void* stream) {
-  MI_REQUIRE(values && enc, "encode12: null pointer");
   MI_REQUIRE(n_px >= 0 && n_px % 2 == 0, "encode12: pixel count must be even, got %lld", (long long)n_px);
   MI_REQUIRE(mi_valid_dtype(in_dtype), "encode12: bad dtype %d", in_dtype);
   if (n_px == 0) return 0;
+  MI_REQUIRE(values && enc, "encode12: null pointer");
   const float k = (float)(4095.0 / (double)mi_scale_factor(in_dtype));
   hipStream_t s = (hipStream_t)stream;
   return dispatch_dtype(in_dtype, [&](auto tag) {

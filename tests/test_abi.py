@@ -1,0 +1,91 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/mi_isp.h
+declares; host-only entry points behave; argument validation fails loudly (no kernel runs)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import isp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mi_isp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_isp_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from taichi_image_amd import _native
+    L = _native.lib()
+    names = declared_symbols()
+    assert len(names) >= 22
+    for n in names:
+        assert hasattr(L, n), f"{n} missing from libmi355_isp.so"
+        assert n in _native.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_native.SIGNATURES) == names
+
+
+def test_host_only_entry_points():
+    from taichi_image_amd import _native, bayer
+    L = _native.lib()
+    assert L.mi_isp_version() >= 1000
+    assert np.array_equal(bayer.bayer_weights(), O.BAYER_KERNELS)
+    assert L.mi_isp_workspace_bytes(3072, 4096) >= 64 * 4 + 8 * 3072 * 4
+    assert L.mi_isp_workspace_bytes(0, 0) == 0
+
+
+def test_argument_validation_reports_errors():
+    from taichi_image_amd import _native
+    L = _native.lib()
+    assert L.mi_isp_decode12(None, None, 4, 1, 0, 0, None) != 0
+    assert b"null" in L.mi_isp_last_error()
+    buf = (ctypes.c_uint8 * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.mi_isp_decode12(p, p, 3, 1, 0, 0, None) != 0           # odd pixel count
+    assert b"even" in L.mi_isp_last_error()
+    assert L.mi_isp_demosaic(p, p, 5, 8, 2, 2, 0, None, None) != 0   # odd height (bayer.py:206)
+    assert b"even size" in L.mi_isp_last_error()
+    assert L.mi_isp_demosaic(p, p, 4, 8, 9, 2, 0, None, None) != 0
+    assert L.mi_isp_transform(p, p, 4, 8, 0, 7, None) != 0           # transverse on non-square
+    with pytest.raises(RuntimeError, match="libmi355_isp"):
+        _native.check(L.mi_isp_resize_bilinear(p, p, 4, 4, 2, 2, 0.0, 0.5, 2, 2, None))
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the public ops raise instead of computing on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import taichi_image_amd as ti
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ti.packed.decode12(np.zeros(6, np.uint8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ti.bayer.bayer_to_rgb(np.zeros((4, 4), np.float32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "taichi_image_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+    assert "oracle" not in open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0] \
+        if os.path.exists(os.path.join(ROOT, "bench.py")) else True
+
+
+def test_dtype_tokens():
+    import torch
+    from taichi_image_amd import types
+    assert types.as_dtype("f16") is types.f16 and types.as_dtype(np.float16) is types.f16
+    assert types.as_dtype(torch.float16) is types.f16 and types.as_dtype(np.dtype("uint16")) is types.u16
+    assert types.as_dtype("float32") is types.f32 and types.as_dtype(torch.uint8) is types.u8
+    with pytest.raises(KeyError):
+        types.as_dtype(np.float64)
+    with pytest.raises(ValueError):
+        types.ti_type([1, 2, 3])
+    assert types.scale_factor[types.u16] == 65535

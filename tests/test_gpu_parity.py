@@ -151,7 +151,10 @@ def test_demosaic_constant_invariance_full_size(ti, dev):
         cfa = torch.full((3072, 4096), val, dtype=dt, device=dev)
         rgb = ti.bayer.bayer_to_rgb(cfa)
         assert rgb.shape == (3072, 4096, 3)
-        assert bool((rgb == cfa[0, 0]).all())
+        if dt == torch.float16:     # every partial sum k*v is exact in fp32
+            assert bool((rgb == cfa[0, 0]).all())
+        else:
+            assert bool(((rgb - cfa[0, 0]).abs() <= 5e-7 * val).all())
 
 
 def test_demosaic_torch_container(ti, rng, dev):

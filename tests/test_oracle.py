@@ -1,0 +1,165 @@
+"""CPU tests of the oracle itself: hand-derived known answers, the reference's only assertion
+(test/packed.py:6-15), algebraic properties and the committed golden vectors.  No GPU, no HIP."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import isp_oracle as O
+from tests.util import assert_exact
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+
+
+def test_kat_unpack():
+    a = KAT["decode12_standard"]
+    assert O.decode12(np.array(a["bytes"], np.uint8)).tolist() == a["values"]
+    b = KAT["decode12_ids"]
+    assert O.decode12(np.array(b["bytes"], np.uint8), ids_format=True).tolist() == b["values"]
+    c = KAT["decode16"]
+    assert O.decode16(np.array(c["bytes"], np.uint8)).tolist() == c["values"]
+    s = KAT["scaled_f16_bits"]
+    v = np.array(s["values"] + [0] * (len(s["values"]) % 2), np.uint16)
+    d = O.decode12(O.encode12(v), "f16", scaled=True).view(np.uint16)[: len(s["values"])]
+    assert d.tolist() == s["bits"]
+
+
+def test_kat_bayer_tables():
+    assert [list(t) for t in O.DIAMOND] == KAT["tap_order"]
+    assert O.BAYER_KERNELS.tolist() == KAT["bayer_kernels"]
+    assert np.all(O.BAYER_KERNELS.sum(axis=1) == 16)
+    for k, v in KAT["kernel_patterns"].items():
+        assert list(O.KERNEL_PATTERN[int(k)]) == v
+    for k, v in KAT["pixel_orders"].items():
+        assert list(O.PIXEL_ORDER[int(k)]) == v
+
+
+def test_reference_roundtrip(rng):
+    """taichi_image/test/packed.py:6-15."""
+    for _ in range(100):
+        size = int(rng.integers(0, 1000)) * 2
+        x = rng.integers(0, 2 ** 12, size=size).astype(np.uint16)
+        assert np.all(O.decode12(O.encode12(x)) == x)
+
+
+def test_scaled_roundtrip_is_identity_on_12bit_grid(rng):
+    v = rng.integers(0, 4096, 2000).astype(np.uint16)
+    for dt in ("f32", "u16"):
+        x = O.decode12(O.encode12(v), dt, scaled=True)
+        assert np.array_equal(O.decode12(O.encode12(x, scaled=True)), v), dt
+
+
+@pytest.mark.parametrize("p", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype,val", [("u8", 200), ("u16", 1000), ("f16", 0.37), ("f32", 0.123)])
+def test_constant_cfa_invariance(p, dtype, val):
+    """Channel weights sum to 16 over any in-bounds tap subset the borders produce, so a
+    constant CFA stays constant.  (Integer outputs may drop one LSB: truncation of v/s*s.)"""
+    cfa = np.full((12, 10), val, O.NP_DTYPE[dtype])
+    rgb = O.bayer_to_rgb(cfa, p)
+    if dtype == "f16":      # k*v is exact in fp32 for every partial sum -> exactly constant
+        assert np.all(rgb == cfa[0, 0])
+    elif dtype == "f32":    # products round: constant to within an ulp or two
+        assert np.allclose(rgb, cfa[0, 0], rtol=5e-7, atol=0)
+    else:
+        assert np.all((rgb.astype(int) - int(val)) >= -1) and np.all(rgb <= val)
+        assert len(np.unique(rgb)) == 1
+
+
+def test_demosaic_site_passthrough(rng):
+    """The identity kernel: each pixel's own colour passes through untouched (interior)."""
+    for p in range(4):
+        cfa = rng.random((16, 20), dtype=np.float32)
+        rgb = O.bayer_to_rgb(cfa, p)
+        order = O.PIXEL_ORDER[p]
+        for site, (i, k) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+            ch = order[site]
+            assert np.array_equal(rgb[i::2, k::2, ch], np.clip(cfa[i::2, k::2], 0, 1)), (p, site)
+
+
+def test_mosaic_demosaic_psnr(rng):
+    """Workflow of taichi_image/test/bayer.py:56-65 on a smooth scene, all four patterns."""
+    r = np.arange(64)[:, None] / 64
+    c = np.arange(96)[None, :] / 96
+    img = np.stack([0.5 + 0.4 * np.sin(5 * r + k) * np.cos(4 * c) for k in range(3)], -1).astype(np.float32)
+    for p in range(4):
+        out = O.bayer_to_rgb(O.rgb_to_bayer(img, p), p)
+        mse = np.mean((out[4:-4, 4:-4] - img[4:-4, 4:-4]) ** 2)
+        assert 10 * np.log10(1.0 / mse) > 45, p
+
+
+def test_resize_identity_and_clamp(rng):
+    src = rng.random((9, 7, 3), dtype=np.float32)
+    assert_exact(O.resize_bilinear(src, (7, 9), 1.0), src)
+    up = O.resize_bilinear(src, (14, 18), 2.0)
+    assert_exact(up[::2, ::2], src)
+    assert np.array_equal(up[17, ::2], src[8])          # clamp-to-edge: last half-row repeats the edge
+
+
+def test_isp_output_size_rounding():
+    assert O.isp_output_size(3072, 4096, 1920) == ((1920, 1440), 1920 / 4096)
+    assert O.isp_output_size(5, 10, scale=0.5)[0] == (5, 2)     # round(2.5) == 2 (banker's)
+
+
+def test_transform_identities(rng):
+    x = (rng.random((6, 10, 3)) * 255).astype(np.uint8)
+    T = O.transform
+    assert np.array_equal(T(T(x, "rotate_90"), "rotate_270"), x)
+    assert np.array_equal(T(T(x, "rotate_180"), "rotate_180"), x)
+    assert np.array_equal(T(x, "transpose"), x.transpose(1, 0, 2))
+    assert np.array_equal(T(x, "flip_vert"), x[::-1])
+    assert np.array_equal(T(x, "flip_horiz"), x[:, ::-1])
+    assert np.array_equal(T(x, "rotate_90"), np.rot90(x, -1))
+    sq = x[:6, :6]
+    assert np.array_equal(T(T(sq, "transverse"), "transverse"), sq)
+    with pytest.raises(AssertionError):
+        T(x, "transverse")
+
+
+def test_metering_bounds_blended_twice(rng):
+    """camera_isp.py:156-157 then :165: the new bounds enter with weight (1-alpha)^2."""
+    im = rng.random((32, 32, 3), dtype=np.float32).astype(np.float16)
+    prev = np.array([0.25, 0.5, -3, -0.1, -1, 0.4, 0.4, 0.4, 0.4], np.float32)
+    a = 0.7
+    m = O.metering_images([im], a, prev)
+    s = im[::8, ::8].astype(np.float32)
+    lo, hi = s.min(), s.max()
+    assert np.isclose(m[0], (1 - a) ** 2 * lo + (1 - (1 - a) ** 2) * prev[0], rtol=1e-6)
+    assert np.isclose(m[1], (1 - a) ** 2 * hi + (1 - (1 - a) ** 2) * prev[1], rtol=1e-6)
+    first = O.metering_images([im], 0.0, np.zeros(9, np.float32))
+    assert first[0] == lo and first[1] == hi
+
+
+def test_sharded_metering_equals_whole(rng):
+    """The split used for multi-GPU: partials of two shards combine to the single-shard result."""
+    ims = [rng.random((40, 48, 3), dtype=np.float32).astype(np.float16) for _ in range(4)]
+    prev = np.array([0.1, 0.9, -3, -0.1, -1, 0.4, 0.4, 0.4, 0.4], np.float32)
+    a = 0.9
+    whole = O.metering_images(ims, a, prev)
+    b0, b1 = O.metering_partials_bounds(ims[:1]), O.metering_partials_bounds(ims[1:])
+    raw = np.array([min(b0[0], b1[0]), max(b0[1], b1[1])], np.float32)
+    b = (raw + np.float32(a) * (prev[:2] - raw)).astype(np.float32)
+    (p0, n0), (p1, n1) = O.metering_partials_sums(ims[:1], b), O.metering_partials_sums(ims[1:], b)
+    part = np.array([min(p0[0], p1[0]), max(p0[1], p1[1]), *(p0[2:] + p1[2:])])
+    got = O.metering_finish(prev, b, part, n0 + n1, a)
+    assert np.allclose(got, whole, rtol=1e-6, atol=1e-7)
+
+
+def test_stateless_reinhard_range_and_quirk(rng):
+    img = rng.random((24, 32, 3), dtype=np.float32).astype(np.float16)
+    out, info = O.tonemap_reinhard(img, dtype="f32", return_intermediates=True)
+    assert out.min() == 0.0 and out.max() == 1.0
+    assert info["Bmax"] >= 0 and info["Bmin"] <= 0          # B = (log_min, -log_max) sign quirk
+    out8 = O.tonemap_reinhard(img, dtype="u8")
+    assert out8.dtype == np.uint8 and out8.max() == 255
+
+
+def test_golden_vectors_frozen():
+    """The committed fixtures equal what the oracle produces today (see make_golden.py)."""
+    from tests.golden.make_golden import build
+    gold = np.load(os.path.join(HERE, "golden", "golden_small.npz"))
+    now = build()
+    assert sorted(gold.files) == sorted(now)
+    for k in gold.files:
+        assert_exact(now[k], gold[k], k)
