@@ -44,7 +44,12 @@ static inline bool mi_aligned(const void* p, size_t a) { return (reinterpret_cas
 // the library's definition where the reference is undefined (fptoui poison).
 template <class T> MI_DEV T cast_out(float x);
 template <> MI_DEV float cast_out<float>(float x) { return x; }
-template <> MI_DEV half_t cast_out<half_t>(float x) { return (half_t)x; }
+// f32 -> f16 is a separate RNE conversion of the already-rounded f32 value (what ti.cast of an f32
+// expression does on every Taichi backend).  The empty asm keeps hipcc from folding a preceding
+// multiply into v_fma_mixlo_f16, which rounds the exact product ONCE to f16 and so differs from
+// the two-step result for about 1 in 2^13 values (measured on gfx950).
+MI_DEV float f32_rounded(float x) { asm("" : "+v"(x)); return x; }
+template <> MI_DEV half_t cast_out<half_t>(float x) { return (half_t)f32_rounded(x); }
 template <> MI_DEV uint8_t cast_out<uint8_t>(float x) {
   x = fminf(fmaxf(x, 0.f), 255.f);  // fmaxf(NaN, 0) == 0
   return (uint8_t)(unsigned)x;

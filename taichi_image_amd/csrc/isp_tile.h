@@ -109,7 +109,7 @@ MI_DEV void unpack12x8(uint32_t d0, uint32_t d1, uint32_t d2, bool ids, uint32_t
 }
 
 // scaled write of packed.py:98-100: cast(f32(v) * f32(scale/4095), E)
-template <class E> MI_DEV E decode_scaled(uint32_t v, float k) { return (E)((float)v * k); }
+template <class E> MI_DEV E decode_scaled(uint32_t v, float k) { return cast_out<E>((float)v * k); }
 
 template <class E> MI_DEV void lds_store8(E* p, const E (&v)[8]);
 template <> MI_DEV void lds_store8<half_t>(half_t* p, const half_t (&v)[8]) {
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
           // the reference materialises the demosaiced image in the work dtype (scale 1)
           float x[3];
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) x[ch] = (float)(E)rgb[ch];
+          for (int ch = 0; ch < 3; ++ch) x[ch] = (float)cast_out<E>(rgb[ch]);
           const bool live = k < npx;
           if constexpr (EPI == EPI_MINMAX) {
             if (live) {

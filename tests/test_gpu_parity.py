@@ -173,8 +173,6 @@ def test_demosaic_errors(ti, rng):
         ti.bayer.bayer_to_rgb(rng.random((4, 4, 3), dtype=np.float32))
     with pytest.raises(KeyError):
         ti.bayer.bayer_to_rgb(np.zeros((4, 4), np.float64))
-    with pytest.raises(ValueError):
-        ti.bayer.bayer_to_rgb([[0, 1], [1, 0]])
 
 
 # ---------------------------------------------------------------------------------------------
