@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the camera-ISP hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic frames: BASELINE config 2,
+4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap -> f16 RGB (the stateless chain of the
+reference's test/pipeline.py:26-32), `--frames` frames per rank per step, one frame per HIP
+stream in flight.  Frames are independent, so N ranks shard the batch with no data-path
+collective ("scaling": "weak": per-GPU work is fixed).  Inputs are resident in HBM before the
+timed region; value = total megapixels (sensor pixels) of all ranks / max-over-ranks wall time.
+
+One JSON line is printed by rank 0; besides the driver's contract keys it carries
+  roofline     : the dominant kernel (final map + store pass) timed with events on its stream
+  cpu_baseline : the CPU oracle (a port, NOT the reference's Taichi CPU backend, which cannot be
+                 installed here) timed on this box's host cores, rank 0 at N=1 only
+  kernels_us   : average duration of each of the four data passes
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W = 3072, 4096
+MP = H * W / 1e6
+BYTES_IN = H * W * 3 // 2            # packed-12 frame
+BYTES_OUT_F16 = H * W * 3 * 2        # f16 RGB frame
+ALG_BYTES = BYTES_IN + BYTES_OUT_F16  # 94 371 840 B / frame = 7.5 B/px
+HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def time_passes(frame, out, ws_ptr, device, reps=30):
+    """Average duration (us) of each data pass, events on the stream the kernels run on."""
+    from taichi_image_amd import _native, types
+    L = _native.lib()
+    stream = torch.cuda.current_stream(device)
+    res = []
+    for p in range(4):
+        def launch():
+            _native.check(L.mi_isp_pipeline12_pass(frame.data_ptr(), out.data_ptr(), H, W, 0, 0, None,
+                                                   types.f16.code, types.f16.code, 1.0, 1.0, 0.0, p, ws_ptr,
+                                                   stream.cuda_stream))
+        for _ in range(5):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        e1.synchronize()
+        res.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return res
+
+
+def cpu_baseline(packed_frame: np.ndarray):
+    """The CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+    ncores = os.cpu_count() or 1
+    try:
+        from oracle import c_oracle
+        if c_oracle.available():
+            reps, times = 3, []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                c_oracle.pipeline12_reinhard(packed_frame)
+                times.append(time.perf_counter() - t0)
+            t = float(np.median(times))
+            return {"value": round(MP / t, 3), "unit": "MP/s", "cores": c_oracle.threads(), "kind": "port",
+                    "sample": f"1 full 4096x3072 frame, median of {reps}, C/OpenMP restatement (oracle/isp_oracle.c)"}
+    except ImportError:
+        pass
+    from oracle import isp_oracle as O
+    rows = 512
+    crop = np.ascontiguousarray(packed_frame[:rows])
+    t0 = time.perf_counter()
+    O.pipeline12_reinhard(crop)
+    t = time.perf_counter() - t0
+    return {"value": round(rows * W / 1e6 / t, 3), "unit": "MP/s", "cores": 1, "kind": "port",
+            "sample": f"first {rows} rows of one frame ({rows * W / 1e6:.2f} MP), single-threaded NumPy restatement "
+                      f"(oracle/isp_oracle.py), host has {ncores} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=8, help="frames per rank per step")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams per rank (frames in flight)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from taichi_image_amd import synthetic
+    from taichi_image_amd.pipeline import BatchPipeline
+
+    # distinct synthetic frames per rank (seeds 1234 + k); 4 distinct, cycled
+    n_distinct = min(4, args.frames)
+    host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(n_distinct)]
+    frames = [torch.from_numpy(host[i % n_distinct]).to(device) for i in range(args.frames)]
+    bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        bp(frames)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bp(frames)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_mp = world * args.frames * args.steps * MP
+        value = total_mp / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        passes = time_passes(frames[0], bp.outputs[0], bp.ws.data_ptr(), device)
+        dom_us = passes[3]
+        achieved = ALG_BYTES / (dom_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("pass3_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "megapixels/sec end-to-end ISP, 4096x3072 RGGB12; % HBM roofline",
+            "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 2: 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap (stateless, "
+                                   "gamma 1) -> f16 RGB", "frames_per_rank_per_step": args.frames,
+                       "streams_per_rank": args.streams, "work_dtype": "f16", "sharding": f"frames x{world}, no collective"},
+            "us_per_frame": round(elapsed / (args.frames * args.steps) * 1e6, 2),
+            "pipeline_frac_of_hbm_roofline": round(ALG_BYTES * world * args.frames * args.steps / elapsed / 1e9
+                                                   / (HBM_PEAK_GBS * world), 4),
+            "roofline": {"bound": "hbm", "kernel": "tile_kernel<f16, RGGB, EPI_RH_STORE> (final map + store pass)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ALG_BYTES, "avg_launch_us": round(dom_us, 2)},
+            "kernels_us": {"pass0_bounds": round(passes[0], 2), "pass1_stats": round(passes[1], 2),
+                           "pass2_reinhard_bounds": round(passes[2], 2), "pass3_map_store": round(passes[3], 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host[0])
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,7 @@ struct FinArgs {
   float n_px;           // pixel count for the means
   float alpha;          // ISP lerp weight
   float intensity, la, ca;
+  int round_f16;        // FIN_BOUNDS: round lo/hi to f16 first (bounds were reduced before rounding)
 };
 int finalize(int mode, const FinArgs& a, hipStream_t s);
 

@@ -513,7 +513,8 @@ __global__ __launch_bounds__(EW_THREADS) void finalize_kernel(int mode, const ew
   __syncthreads();
   if (threadIdx.x != 0) return;
 
-  const float lo = (float)tot[0], hi = (float)tot[1];
+  float lo = (float)tot[0], hi = (float)tot[1];
+  if (mode == ew::FIN_BOUNDS && a.round_f16) { lo = (float)(half_t)lo; hi = (float)(half_t)hi; }
   float* fp = a.fp;
   switch (mode) {
     case ew::FIN_BOUNDS:

@@ -265,38 +265,44 @@ MI_DEV void accumulate(const float (&win)[6][12], float (&acc)[3]) {
   });
 }
 
-// in-bounds weight sums for a border pixel (the `t` of bayer.py:143-149)
+// in-bounds weight sums for a border pixel (the `t` of bayer.py:143-149): 0/1 masks for the five
+// row and five column offsets, then t += mask * w over the non-zero compile-time weights (exact
+// small integers in fp32).  No memory access; only strips that touch the image frame run it.
 template <int KIDX>
 MI_DEV void border_weight(int r, int c, int H, int W, float (&t3)[3]) {
-  t3[0] = t3[1] = t3[2] = 0.f;
+  float rm[5], cm[5];
 #pragma unroll
-  for (int t = 0; t < 13; ++t) {
-    const int rr = r + TAP_DR[t], cc = c + TAP_DC[t];
-    if (rr >= 0 && rr < H && cc >= 0 && cc < W) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) t3[ch] += (float)KW[KIDX][t][ch];
-    }
+  for (int d = -2; d <= 2; ++d) {
+    rm[d + 2] = (r + d >= 0 && r + d < H) ? 1.f : 0.f;
+    cm[d + 2] = (c + d >= 0 && c + d < W) ? 1.f : 0.f;
   }
+  t3[0] = t3[1] = t3[2] = 0.f;
+  static_for<0, 13>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const float m = rm[TAP_DR[t] + 2] * cm[TAP_DC[t] + 2];
+    static_for<0, 3>([&](auto cc) {
+      constexpr int ch = decltype(cc)::value;
+      constexpr int w = KW[KIDX][t][ch];
+      if constexpr (w != 0) t3[ch] = __builtin_fmaf(m, (float)w, t3[ch]);
+    });
+  });
 }
 
 // One demosaiced pixel, normalised, colour-corrected and clamped to [0,1] (bayer.py:151-155).
-template <int KIDX, bool EXACT, int I, int K>
-MI_DEV void demosaic_px(const Params& p, const float (&win)[6][12], int r, int c, float (&rgb)[3]) {
+// FAST: the whole strip is interior (every tap in bounds, t == 16) and the CFA scale is 1, so
+// c / (in_scale * t) is the exact multiply by 1/16; no per-pixel branch, no division.
+// Otherwise: true (correctly rounded) division by in_scale * t, t from the in-bounds taps.
+template <int KIDX, bool EXACT, int I, int K, bool FAST>
+MI_DEV void demosaic_px(const Params& p, const float (&win)[6][12], int r, int c, bool strip_interior,
+                        float (&rgb)[3]) {
   float acc[3];
   accumulate<KIDX, EXACT, I, K>(win, acc);
-  const bool interior = r >= 2 && r < p.H - 2 && c >= 2 && c < p.W - 2;
-  if (interior) {
-    if (p.in_scale == 1.f) {
+  if constexpr (FAST) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) acc[ch] *= 0.0625f;           // == / (1 * 16), exact
-    } else {
-      const float d = p.in_scale * 16.f;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] / d;        // correctly rounded division
-    }
+    for (int ch = 0; ch < 3; ++ch) acc[ch] *= 0.0625f;
   } else {
-    float t3[3];
-    border_weight<KIDX>(r, c, p.H, p.W, t3);
+    float t3[3] = {16.f, 16.f, 16.f};
+    if (!strip_interior) border_weight<KIDX>(r, c, p.H, p.W, t3);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] / (p.in_scale * t3[ch]);
   }
@@ -388,33 +394,35 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
   if (active) {
     float win[6][12];
     load_window<E>(lds, tx, ty, win);
-    static_for<0, 2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      float row[24];
-      static_for<0, 8>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        // kernel index is a compile-time function of the strip position and the pattern
-        constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
-        float rgb[3];
-        demosaic_px<KIDX, EXACT, i, k>(p, win, r + i, c + k, rgb);
-        if constexpr (EPI == EPI_STORE) {
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) row[3 * k + ch] = rgb[ch] * p.out_scale;
-        } else {
-          // the reference materialises the demosaiced image in the work dtype (scale 1)
-          float x[3];
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) x[ch] = (float)cast_out<E>(rgb[ch]);
+    // all 13 taps of all 16 pixels in bounds?
+    const bool strip_interior = r >= 2 && r + 1 < p.H - 2 && c >= 2 && c + 7 < p.W - 2;
+    auto strip = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
+      static_for<0, 2>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        float row[24];
+        static_for<0, 8>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          // kernel index is a compile-time function of the strip position and the pattern
+          constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
+          float rgb[3];
+          demosaic_px<KIDX, EXACT, i, k, FAST>(p, win, r + i, c + k, strip_interior, rgb);
           const bool live = k < npx;
-          if constexpr (EPI == EPI_MINMAX) {
+          if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) row[3 * k + ch] = rgb[ch] * p.out_scale;
+          } else if constexpr (EPI == EPI_MINMAX) {
+            // bounds of the work-dtype image: rounding to E is monotone, so it is applied once to
+            // the reduced min / max (finalize) instead of to every pixel
             if (live) {
-              vmin = fminf(vmin, fminf(x[0], fminf(x[1], x[2])));
-              vmax = fmaxf(vmax, fmaxf(x[0], fmaxf(x[1], x[2])));
+              vmin = fminf(vmin, fminf(rgb[0], fminf(rgb[1], rgb[2])));
+              vmax = fmaxf(vmax, fmaxf(rgb[0], fmaxf(rgb[1], rgb[2])));
             }
           } else {
+            // the reference materialises the demosaiced image in the work dtype (scale 1)
             float t[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) t[ch] = norm01(x[ch], lo, inv);
+            for (int ch = 0; ch < 3; ++ch) t[ch] = norm01((float)cast_out<E>(rgb[ch]), lo, inv);
             if constexpr (EPI == EPI_STATS) {
               if (live) st.add(t[0], t[1], t[2]);
             } else {
@@ -432,10 +440,12 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
               }
             }
           }
-        }
+        });
+        if constexpr (EPI == EPI_STORE || EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
       });
-      if constexpr (EPI == EPI_STORE || EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
-    });
+    };
+    if (strip_interior && p.in_scale == 1.f) strip(std::true_type{});
+    else strip(std::false_type{});
   }
 
   if (EPI == EPI_MINMAX || EPI == EPI_RH_MINMAX) {
