@@ -1,0 +1,27 @@
+"""Times one data pass of the fused pipeline with parts switched off (fill / strip compute)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from taichi_image_amd import _native, synthetic, types
+from taichi_image_amd.pipeline import pipeline12_reinhard
+H, W = 3072, 4096
+dev = torch.device("cuda", 0)
+frame = torch.from_numpy(synthetic.synthetic_packed12(0)).to(dev)
+out = torch.empty((H, W, 3), dtype=torch.float16, device=dev)
+pipeline12_reinhard(frame, out=out)
+ws = _native.workspace(H, W, dev)
+L = _native.lib()
+st = torch.cuda.current_stream(dev)
+def t(code, reps=50):
+    def launch():
+        _native.check(L.mi_isp_pipeline12_pass(frame.data_ptr(), out.data_ptr(), H, W, 0, 0, None, types.f16.code,
+                                               types.f16.code, 1.0, 1.0, 0.0, code, ws.data_ptr(), st.cuda_stream))
+    for _ in range(10): launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps): launch()
+    e1.record(st); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+for p in (0, 3):
+    print(f"pass {p}: full {t(p):.1f} us | no fill {t(p + 16):.1f} | no compute {t(p + 32):.1f} | neither {t(p + 48):.1f}")

@@ -111,7 +111,7 @@ static int pipeline_frame(tile::Params p, int pattern, int work_dtype, float int
   ew::FinArgs fa = {};
   fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
   fa.n_px = (float)((int64_t)p.H * p.W); fa.intensity = intensity; fa.la = p.la; fa.ca = p.ca;
-  fa.round_f16 = work_dtype == MI_F16;
+  fa.bounds_post = work_dtype == MI_F16 ? 2 : 1;
   if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_MINMAX, s)) return rc;      // tonemap.py:146
   if (int rc = ew::finalize(ew::FIN_BOUNDS, fa, s)) return rc;
   if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STATS, s)) return rc;       // :147-149
@@ -179,6 +179,8 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
                                       const float* ccm9, int work_dtype, int out_dtype, float gamma,
                                       float light_adapt, float color_adapt, int pass, void* ws, void* stream) {
   MI_REQUIRE(out && ws, "pipeline12_pass: null pointer");
+  const int debug_skip = pass >> 4;      // measurement aid (see tile::Params::debug_skip)
+  pass &= 15;
   MI_REQUIRE(pass >= 0 && pass <= 3, "pipeline12_pass: pass must be 0..3");
   tile::Params p = {};
   if (int rc = pipeline_params(p, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma, light_adapt,
@@ -189,6 +191,10 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
   p.vec_store = vec_store_ok(out, W, out_dtype);
   float* fp = static_cast<float*>(ws);
   p.fp = fp; p.partials = fp + FP_COUNT; p.part_stride = mi_partial_cap(H, W);
+  p.debug_skip = debug_skip;
   static const int epi[4] = {tile::EPI_MINMAX, tile::EPI_STATS, tile::EPI_RH_MINMAX, tile::EPI_RH_STORE};
   return tile::launch(p, work_dtype, pattern, epi[pass], (hipStream_t)stream);
 }
+
+namespace tile { int occupancy_rggb(int epi); }
+extern "C" int mi_isp_debug_occupancy(int epi) { return tile::occupancy_rggb(epi); }

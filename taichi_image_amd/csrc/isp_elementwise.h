@@ -27,7 +27,7 @@ struct FinArgs {
   float n_px;           // pixel count for the means
   float alpha;          // ISP lerp weight
   float intensity, la, ca;
-  int round_f16;        // FIN_BOUNDS: round lo/hi to f16 first (bounds were reduced before rounding)
+  int bounds_post;      // FIN_BOUNDS: 0 = bounds are final; 1 = clamp to [0,1]; 2 = clamp, then round to f16
 };
 int finalize(int mode, const FinArgs& a, hipStream_t s);
 

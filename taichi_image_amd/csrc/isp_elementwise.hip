@@ -514,7 +514,11 @@ __global__ __launch_bounds__(EW_THREADS) void finalize_kernel(int mode, const ew
   if (threadIdx.x != 0) return;
 
   float lo = (float)tot[0], hi = (float)tot[1];
-  if (mode == ew::FIN_BOUNDS && a.round_f16) { lo = (float)(half_t)lo; hi = (float)(half_t)hi; }
+  if (mode == ew::FIN_BOUNDS && a.bounds_post > 0) {
+    // tile bounds pass: reduced before the clamp / work-dtype rounding of bayer.py:155,134
+    lo = fminf(fmaxf(lo, 0.f), 1.f); hi = fminf(fmaxf(hi, 0.f), 1.f);
+    if (a.bounds_post > 1) { lo = (float)(half_t)lo; hi = (float)(half_t)hi; }
+  }
   float* fp = a.fp;
   switch (mode) {
     case ew::FIN_BOUNDS:

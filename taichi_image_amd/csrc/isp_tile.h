@@ -1,16 +1,27 @@
 // LDS-tiled Bayer demosaic (bayer.py:115-177 of the reference) with pluggable sources and
 // epilogues.  One 256-thread block (4 wave64) produces a 128x32-pixel output tile:
-//   1. fill : the CFA tile + 2-px halo is staged in LDS in the work type E (f16 or f32); packed
-//             12/16-bit sources are unpacked on the way (packed.py:24-44,149-157), 8 pixels
-//             (12 or 16 coalesced bytes) per lane;
+//   1. fill : the CFA tile + 2-px halo is staged in LDS as fp32 holding the work-dtype values
+//             (E = f16 or f32: the values are rounded to E exactly where the reference stores its
+//             CFA image, then widened).  Packed 12/16-bit sources are unpacked on the way
+//             (packed.py:24-44,149-157), 8 pixels (12 or 16 coalesced bytes) per lane, every load
+//             of a lane issued before the first use;
 //   2. strip: every lane owns a 2-row x 8-col strip, reads its 6x12 window from LDS once
-//             (b32 + b128 + b32 per row) and evaluates the four 13-tap diamond kernels with
+//             (b64 + 2 x b128 + b64 per row) and evaluates the four 13-tap diamond kernels with
 //             compile-time weights, accumulating in fp32 in the reference's tap order;
-//   3. epilogue: store RGB (16-byte stores), or feed the tonemap reductions / final map of the
-//             fused config-2 pipeline without ever writing the intermediate RGB image.
-// Arithmetic contract: the demosaic is bit-exact against oracle/isp_oracle.py:bayer_to_rgb
-// (same operation order; products of <=16-bit inputs with the integer weights are exact in
-// fp32, so fmaf == mul+add for E = f16; E = f32 uses separate mul and add).
+//   3. epilogue per strip row: store RGB (16-byte stores), or feed the tonemap reductions / final
+//             map of the fused config-2 pipeline without ever writing the intermediate RGB image.
+//
+// Arithmetic contract: the demosaic is bit-exact against oracle/isp_oracle.py:bayer_to_rgb.
+// The accumulation uses the weights w/16 (an exact power-of-two scaling that commutes with every
+// rounding in the chain), so an interior pixel of a scale-1 CFA is finished after the last FMA;
+// every other pixel is fixed up as (acc*16) / (in_scale * t) with a correctly rounded division.
+// Products of <=16-bit inputs with the weights are exact in fp32, so fmaf == mul-then-add for
+// E = f16; E = f32 keeps separate mul and add.
+//
+// Measured on gfx950 (scratch/fma_bench3.hip): the vector issue rate is ~1 wave-instruction/ns per
+// SIMD only while the instruction stream stays under ~4.4 bytes/ns per SIMD, i.e. with 4-byte
+// encodings; long bodies of 8-byte encodings run at ~0.55/ns.  The strip code is therefore written
+// to compile to VOP2 forms (v_fmac_f32 with SGPR weights) and as few instructions as possible.
 #pragma once
 #include "isp_common.h"
 #include "isp_math.h"
@@ -36,10 +47,7 @@ constexpr int LDS_COLS = TILE_W + 16;                 // image cols [c0-8, c0+TI
 constexpr int LDS_ROWS = TILE_H + 4;                  // image rows [r0-2, r0+TILE_H+2)
 constexpr int UNITS = LDS_COLS / 8;                   // 8-px load units per LDS row
 constexpr int THREADS = 256;
-
-template <class E> struct Pitch;                      // LDS row pitch in elements (16-B multiple)
-template <> struct Pitch<half_t> { static constexpr int value = LDS_COLS + 8; };
-template <> struct Pitch<float> { static constexpr int value = LDS_COLS + 4; };
+constexpr int PITCH = LDS_COLS + 4;                   // LDS row pitch in floats (16-B multiple)
 
 enum SrcKind { SRC_CFA_U8 = 0, SRC_CFA_U16 = 1, SRC_CFA_F16 = 2, SRC_CFA_F32 = 3,
                SRC_PACKED12 = 4, SRC_PACKED12_IDS = 5, SRC_PACKED16 = 6 };
@@ -62,6 +70,7 @@ struct Params {
   float k_decode;         // f32(scale(E)/4095) or f32(scale(E)/65535) for packed sources
   float out_scale;        // scale_factor of the output dtype
   float gamma_inv, la, ca;
+  int debug_skip;         // measurement aid: bit 0 skips the fill, bit 1 skips the strip compute
 };
 
 // 13-tap diamond, reference order (bayer.py:15-27): (d_row, d_col)
@@ -98,26 +107,32 @@ MI_DEV void unpack_pair(uint32_t w, bool ids, uint32_t& p0, uint32_t& p1) {
 
 // 8 pixels from 12 packed bytes held in three little-endian dwords
 MI_DEV void unpack12x8(uint32_t d0, uint32_t d1, uint32_t d2, bool ids, uint32_t (&v)[8]) {
-  const uint32_t w0 = d0 & 0xFFFFFFu;
-  const uint32_t w1 = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
-  const uint32_t w2 = (d1 >> 16) | ((d2 & 0xFFu) << 16);
-  const uint32_t w3 = d2 >> 8;
-  unpack_pair(w0, ids, v[0], v[1]);
-  unpack_pair(w1, ids, v[2], v[3]);
-  unpack_pair(w2, ids, v[4], v[5]);
-  unpack_pair(w3, ids, v[6], v[7]);
+  if (!ids) {
+    // the standard layout is plain little-endian bit packing: pixel k = bits [12k, 12k+12)
+    v[0] = d0 & 0xFFFu;
+    v[1] = (d0 >> 12) & 0xFFFu;
+    v[2] = __builtin_amdgcn_alignbit(d1, d0, 24) & 0xFFFu;
+    v[3] = (d1 >> 4) & 0xFFFu;
+    v[4] = (d1 >> 16) & 0xFFFu;
+    v[5] = __builtin_amdgcn_alignbit(d2, d1, 28) & 0xFFFu;
+    v[6] = (d2 >> 8) & 0xFFFu;
+    v[7] = d2 >> 20;
+  } else {
+    const uint32_t w0 = d0 & 0xFFFFFFu;
+    const uint32_t w1 = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
+    const uint32_t w2 = (d1 >> 16) | ((d2 & 0xFFu) << 16);
+    const uint32_t w3 = d2 >> 8;
+    unpack_pair(w0, true, v[0], v[1]);
+    unpack_pair(w1, true, v[2], v[3]);
+    unpack_pair(w2, true, v[4], v[5]);
+    unpack_pair(w3, true, v[6], v[7]);
+  }
 }
 
-// scaled write of packed.py:98-100: cast(f32(v) * f32(scale/4095), E)
-template <class E> MI_DEV E decode_scaled(uint32_t v, float k) { return cast_out<E>((float)v * k); }
+// scaled write of packed.py:98-100, cast(f32(v) * f32(scale/4095), E), widened back to fp32
+template <class E> MI_DEV float decode_scaled(uint32_t v, float k) { return (float)cast_out<E>((float)v * k); }
 
-template <class E> MI_DEV void lds_store8(E* p, const E (&v)[8]);
-template <> MI_DEV void lds_store8<half_t>(half_t* p, const half_t (&v)[8]) {
-  typedef half_t h8 __attribute__((ext_vector_type(8)));
-  h8 x = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-  *reinterpret_cast<h8*>(p) = x;
-}
-template <> MI_DEV void lds_store8<float>(float* p, const float (&v)[8]) {
+MI_DEV void lds_store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
@@ -126,9 +141,9 @@ template <> MI_DEV void lds_store8<float>(float* p, const float (&v)[8]) {
 // phase 1: fill the LDS tile.  LDS (lr, lc) <-> image (rb + lr, cb + lc), rb = r0-2, cb = c0-8.
 // Out-of-image elements are zero (they contribute 0*w, an exact no-op, to the accumulators).
 // ---------------------------------------------------------------------------------------------
+// General packed path: any width / alignment, byte loads.
 template <class E>
-MI_DEV void fill_packed(const Params& p, E* lds, int rb, int cb) {
-  constexpr int PITCH = Pitch<E>::value;
+MI_DEV void fill_packed(const Params& p, float* lds, int rb, int cb) {
   const uint8_t* base = static_cast<const uint8_t*>(p.src);
   const bool is16 = p.src_kind == SRC_PACKED16;
   const bool ids = p.src_kind == SRC_PACKED12_IDS;
@@ -136,101 +151,118 @@ MI_DEV void fill_packed(const Params& p, E* lds, int rb, int cb) {
   for (int u = threadIdx.x; u < LDS_ROWS * UNITS; u += THREADS) {
     const int lr = u / UNITS, lu = u - lr * UNITS;
     const int r = rb + lr, c = cb + lu * 8;
-    E out[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = (E)0.f;
-    if (r >= 0 && r < p.H && c >= 0 && c < p.W) {
-      uint32_t v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = 0;
-      const uint8_t* rowp = base + (size_t)r * pitch;
-      const bool whole = c + 8 <= p.W;
-      if (!is16) {
-        const uint8_t* q = rowp + (size_t)c * 3 / 2;          // c % 8 == 0 -> 12-byte multiple
-        if (whole && p.src_fast) {
-          const uint32_t* q32 = reinterpret_cast<const uint32_t*>(q);
-          unpack12x8(q32[0], q32[1], q32[2], ids, v);
-        } else {
-          const int npair = whole ? 4 : (p.W - c) / 2;        // W is even
-          for (int j = 0; j < npair; ++j) {
-            const uint32_t w = q[3 * j] | (q[3 * j + 1] << 8) | (q[3 * j + 2] << 16);
-            unpack_pair(w, ids, v[2 * j], v[2 * j + 1]);
-          }
+    float* dst = lds + lr * PITCH + lu * 8;
+    const bool inside = r >= 0 && r < p.H && c >= 0 && c < p.W;
+    const int n = inside ? (c + 8 <= p.W ? 8 : p.W - c) : 0;     // W is even
+    const uint8_t* rowp = base + (size_t)(inside ? r : 0) * pitch;
+    if (!is16) {
+      const uint8_t* q = rowp + (size_t)(inside ? c : 0) * 3 / 2;  // c % 8 == 0 -> 12-byte multiple
+      for (int j = 0; j < 4; ++j) {
+        uint32_t a = 0, b = 0;
+        if (2 * j < n) {
+          const uint32_t w = q[3 * j] | (q[3 * j + 1] << 8) | (q[3 * j + 2] << 16);
+          unpack_pair(w, ids, a, b);
         }
-      } else {
-        const uint8_t* q = rowp + (size_t)c * 2;
-        if (whole && p.src_fast) {
-          const uint4 d = *reinterpret_cast<const uint4*>(q);  // little-endian u16 pairs
-          v[0] = d.x & 0xFFFFu; v[1] = d.x >> 16; v[2] = d.y & 0xFFFFu; v[3] = d.y >> 16;
-          v[4] = d.z & 0xFFFFu; v[5] = d.z >> 16; v[6] = d.w & 0xFFFFu; v[7] = d.w >> 16;
-        } else {
-          const int n = whole ? 8 : p.W - c;
-          for (int j = 0; j < n; ++j) v[j] = q[2 * j] | (q[2 * j + 1] << 8);
-        }
+        dst[2 * j] = decode_scaled<E>(a, p.k_decode);
+        dst[2 * j + 1] = decode_scaled<E>(b, p.k_decode);
       }
-      const int n = whole ? 8 : p.W - c;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = i < n ? decode_scaled<E>(v[i], p.k_decode) : (E)0.f;
+    } else {
+      const uint8_t* q = rowp + (size_t)(inside ? c : 0) * 2;
+      for (int j = 0; j < 8; ++j) {
+        uint32_t a = 0;
+        if (j < n) a = q[2 * j] | (q[2 * j + 1] << 8);
+        dst[j] = decode_scaled<E>(a, p.k_decode);
+      }
     }
-    lds_store8<E>(lds + lr * PITCH + lu * 8, out);
   }
 }
 
-template <class E, class S>
-MI_DEV void fill_plain(const Params& p, E* lds, int rb, int cb) {
-  constexpr int PITCH = Pitch<E>::value;
+// Fast path (W % 8 == 0, aligned base): every unit is either wholly inside the image or wholly
+// outside.  All global loads of a lane (up to 3 units = 36/48 bytes) are issued before the first
+// use, so one memory latency is paid per tile instead of one per unit; an all-zero unit decodes to
+// zeros, so out-of-image units need no branch after the load.
+template <class E>
+MI_DEV void fill_packed_fast(const Params& p, float* lds, int rb, int cb) {
+  constexpr int NUNITS = LDS_ROWS * UNITS;
+  constexpr int NIT = (NUNITS + THREADS - 1) / THREADS;
+  static_assert(UNITS == 18 && NUNITS < 65536 / 4, "magic division below assumes 18 units per row");
+  const uint8_t* base = static_cast<const uint8_t*>(p.src);
+  const bool is16 = p.src_kind == SRC_PACKED16;
+  const bool ids = p.src_kind == SRC_PACKED12_IDS;
+  const size_t pitch = is16 ? (size_t)p.W * 2 : (size_t)p.W * 3 / 2;
+  uint4 raw[NIT];
+  int off[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int u = threadIdx.x + it * THREADS;
+    const int lr = (u * 3641) >> 16;                 // u / 18 for u < 16384
+    const int lu = u - lr * UNITS;
+    const int r = rb + lr, c = cb + lu * 8;
+    off[it] = u < NUNITS ? lr * PITCH + lu * 8 : -1;
+    raw[it] = make_uint4(0, 0, 0, 0);
+    if (u < NUNITS && r >= 0 && r < p.H && c >= 0 && c < p.W) {
+      const uint8_t* rowp = base + (size_t)r * pitch;
+      if (!is16) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(rowp + (size_t)c * 3 / 2);
+        raw[it].x = q[0]; raw[it].y = q[1]; raw[it].z = q[2];
+      } else {
+        raw[it] = *reinterpret_cast<const uint4*>(rowp + (size_t)c * 2);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (off[it] < 0) continue;
+    uint32_t v[8];
+    const uint4 d = raw[it];
+    if (!is16) {
+      unpack12x8(d.x, d.y, d.z, ids, v);
+    } else {
+      v[0] = d.x & 0xFFFFu; v[1] = d.x >> 16; v[2] = d.y & 0xFFFFu; v[3] = d.y >> 16;
+      v[4] = d.z & 0xFFFFu; v[5] = d.z >> 16; v[6] = d.w & 0xFFFFu; v[7] = d.w >> 16;
+    }
+    float out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = decode_scaled<E>(v[i], p.k_decode);
+    lds_store8(lds + off[it], out);
+  }
+}
+
+// Plain CFA images (u8 / u16 / f16 / f32): coalesced scalar loads, exact widening to fp32.
+template <class S>
+MI_DEV void fill_plain(const Params& p, float* lds, int rb, int cb) {
   const S* src = static_cast<const S*>(p.src);
   constexpr int NEED = TILE_W + 4;                     // image cols [c0-2, c0+TILE_W+2)
+  static_assert(NEED == 132 && LDS_ROWS == 36, "magic division below assumes 36 x 132");
   for (int i = threadIdx.x; i < LDS_ROWS * NEED; i += THREADS) {
-    const int lr = i / NEED, k = i - lr * NEED;
+    const int lr = (i * 993) >> 17;                    // i / 132 for i < 36 * 132
+    const int k = i - lr * NEED;
     const int lc = k + 6;                              // c0-2 == cb+6
     const int r = rb + lr, c = cb + lc;
     float v = 0.f;
     if (r >= 0 && r < p.H && c >= 0 && c < p.W) v = (float)src[(size_t)r * p.W + c];
-    lds[lr * PITCH + lc] = (E)v;
+    lds[lr * PITCH + lc] = v;
   }
 }
 
-template <class E> MI_DEV void fill_tile(const Params& p, E* lds, int rb, int cb);
-template <> MI_DEV void fill_tile<half_t>(const Params& p, half_t* lds, int rb, int cb) {
+template <class E>
+MI_DEV void fill_tile(const Params& p, float* lds, int rb, int cb) {
   switch (p.src_kind) {
-    case SRC_CFA_U8: fill_plain<half_t, uint8_t>(p, lds, rb, cb); break;   // 0..255 exact in f16
-    case SRC_CFA_F16: fill_plain<half_t, half_t>(p, lds, rb, cb); break;
-    default: fill_packed<half_t>(p, lds, rb, cb); break;
-  }
-}
-template <> MI_DEV void fill_tile<float>(const Params& p, float* lds, int rb, int cb) {
-  switch (p.src_kind) {
-    case SRC_CFA_U16: fill_plain<float, uint16_t>(p, lds, rb, cb); break;
-    case SRC_CFA_F32: fill_plain<float, float>(p, lds, rb, cb); break;
-    case SRC_CFA_U8: fill_plain<float, uint8_t>(p, lds, rb, cb); break;
-    case SRC_CFA_F16: fill_plain<float, half_t>(p, lds, rb, cb); break;
-    default: fill_packed<float>(p, lds, rb, cb); break;
+    case SRC_CFA_U8: fill_plain<uint8_t>(p, lds, rb, cb); break;
+    case SRC_CFA_U16: fill_plain<uint16_t>(p, lds, rb, cb); break;
+    case SRC_CFA_F16: fill_plain<half_t>(p, lds, rb, cb); break;
+    case SRC_CFA_F32: fill_plain<float>(p, lds, rb, cb); break;
+    default:
+      if (p.src_fast) fill_packed_fast<E>(p, lds, rb, cb);
+      else fill_packed<E>(p, lds, rb, cb);
+      break;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// phase 2: the lane's 6 x 12 window, LDS -> registers
+// phase 2: the lane's 6 x 12 window, LDS -> registers (window origin = image (r-2, c-2))
 // ---------------------------------------------------------------------------------------------
-template <class E> MI_DEV void load_window(const E* lds, int tx, int ty, float (&win)[6][12]);
-template <> MI_DEV void load_window<half_t>(const half_t* lds, int tx, int ty, float (&win)[6][12]) {
-  constexpr int PITCH = Pitch<half_t>::value;
-  typedef half_t h2 __attribute__((ext_vector_type(2)));
-  typedef half_t h8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const half_t* rp = lds + (2 * ty + k) * PITCH + 8 * tx + 6;
-    const h2 a = *reinterpret_cast<const h2*>(rp);
-    const h8 b = *reinterpret_cast<const h8*>(rp + 2);
-    const h2 c = *reinterpret_cast<const h2*>(rp + 10);
-    win[k][0] = (float)a[0]; win[k][1] = (float)a[1];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) win[k][2 + j] = (float)b[j];
-    win[k][10] = (float)c[0]; win[k][11] = (float)c[1];
-  }
-}
-template <> MI_DEV void load_window<float>(const float* lds, int tx, int ty, float (&win)[6][12]) {
-  constexpr int PITCH = Pitch<float>::value;
+MI_DEV void load_window(const float* lds, int tx, int ty, float (&win)[6][12]) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const float* rp = lds + (2 * ty + k) * PITCH + 8 * tx + 6;
@@ -245,9 +277,8 @@ template <> MI_DEV void load_window<float>(const float* lds, int tx, int ty, flo
   }
 }
 
-// filter_at (bayer.py:138-155) for the pixel at strip position (i, k): sequential fp32
-// accumulation over the non-zero taps in reference order.  EXACT: products are exact in fp32,
-// so a fused multiply-add gives the same bits as mul-then-add.
+// filter_at (bayer.py:138-155) for the pixel at strip position (I, K): sequential fp32 accumulation
+// over the non-zero taps in reference order with the weights w/16.
 template <int KIDX, bool EXACT, int I, int K>
 MI_DEV void accumulate(const float (&win)[6][12], float (&acc)[3]) {
   acc[0] = acc[1] = acc[2] = 0.f;
@@ -256,10 +287,11 @@ MI_DEV void accumulate(const float (&win)[6][12], float (&acc)[3]) {
     const float x = win[I + 2 + TAP_DR[t]][K + 2 + TAP_DC[t]];
     static_for<0, 3>([&](auto cc) {
       constexpr int ch = decltype(cc)::value;
-      constexpr int w = KW[KIDX][t][ch];
-      if constexpr (w != 0) {
-        if constexpr (EXACT) acc[ch] = __builtin_fmaf(x, (float)w, acc[ch]);
-        else acc[ch] = acc[ch] + x * (float)w;
+      constexpr int wi = KW[KIDX][t][ch];
+      constexpr float w = (float)wi * 0.0625f;
+      if constexpr (wi != 0) {
+        if constexpr (EXACT) acc[ch] = __builtin_fmaf(x, w, acc[ch]);
+        else acc[ch] = acc[ch] + x * w;
       }
     });
   });
@@ -286,34 +318,6 @@ MI_DEV void border_weight(int r, int c, int H, int W, float (&t3)[3]) {
       if constexpr (w != 0) t3[ch] = __builtin_fmaf(m, (float)w, t3[ch]);
     });
   });
-}
-
-// One demosaiced pixel, normalised, colour-corrected and clamped to [0,1] (bayer.py:151-155).
-// FAST: the whole strip is interior (every tap in bounds, t == 16) and the CFA scale is 1, so
-// c / (in_scale * t) is the exact multiply by 1/16; no per-pixel branch, no division.
-// Otherwise: true (correctly rounded) division by in_scale * t, t from the in-bounds taps.
-template <int KIDX, bool EXACT, int I, int K, bool FAST>
-MI_DEV void demosaic_px(const Params& p, const float (&win)[6][12], int r, int c, bool strip_interior,
-                        float (&rgb)[3]) {
-  float acc[3];
-  accumulate<KIDX, EXACT, I, K>(win, acc);
-  if constexpr (FAST) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) acc[ch] *= 0.0625f;
-  } else {
-    float t3[3] = {16.f, 16.f, 16.f};
-    if (!strip_interior) border_weight<KIDX>(r, c, p.H, p.W, t3);
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] / (p.in_scale * t3[ch]);
-  }
-  if (p.has_ccm) {
-    const float a = acc[0], b = acc[1], d = acc[2];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-      acc[ch] = (p.ccm[3 * ch] * a + p.ccm[3 * ch + 1] * b) + p.ccm[3 * ch + 2] * d;
-  }
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) rgb[ch] = fminf(fmaxf(acc[ch], 0.f), 1.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -360,21 +364,20 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 // ---------------------------------------------------------------------------------------------
 template <class E, int PR, int PC, int EPI>
 __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
-  constexpr int PITCH = Pitch<E>::value;
   constexpr bool EXACT = sizeof(E) == 2;
-  __shared__ __attribute__((aligned(16))) E lds[LDS_ROWS * PITCH];
+  __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * PITCH];
   __shared__ float red[4][8];
 
   const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
   const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
   const int r0 = by * TILE_H, c0 = bx * TILE_W;
 
-  fill_tile<E>(p, lds, r0 - 2, c0 - 8);
+  if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
   __syncthreads();
 
   const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
   const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
-  const bool active = r < p.H && c < p.W;               // H, W even -> both rows, pixel pairs in
+  const bool active = r < p.H && c < p.W && !(p.debug_skip & 2);   // H, W even -> both rows, pixel pairs in
   const int npx = active ? (p.W - c < 8 ? p.W - c : 8) : 0;
 
   // tonemap scalars (uniform loads); unused ones are dead code per EPI
@@ -393,36 +396,68 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
 
   if (active) {
     float win[6][12];
-    load_window<E>(lds, tx, ty, win);
-    // all 13 taps of all 16 pixels in bounds?
-    const bool strip_interior = r >= 2 && r + 1 < p.H - 2 && c >= 2 && c + 7 < p.W - 2;
-    auto strip = [&](auto fast_c) {
-      constexpr bool FAST = decltype(fast_c)::value;
-      static_for<0, 2>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        float row[24];
+    load_window(lds, tx, ty, win);
+    // every tap of all 16 pixels in bounds, and c / (in_scale * t) == c / 16 ?
+    const bool fast = p.in_scale == 1.f && r >= 2 && r + 1 < p.H - 2 && c >= 2 && c + 7 < p.W - 2;
+
+    static_for<0, 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      float v[24];                                    // the row's 8 px x RGB, normalised
+      static_for<0, 8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
+        float acc[3];
+        accumulate<KIDX, EXACT, i, k>(win, acc);
+        v[3 * k] = acc[0]; v[3 * k + 1] = acc[1]; v[3 * k + 2] = acc[2];
+      });
+      if (!fast) {
+        // border strips / CFAs with scale != 1: c / (in_scale * t), correctly rounded, with
+        // c == acc * 16 exactly and t the in-bounds weight sum (16 when every tap is in bounds)
         static_for<0, 8>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
-          // kernel index is a compile-time function of the strip position and the pattern
           constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
-          float rgb[3];
-          demosaic_px<KIDX, EXACT, i, k, FAST>(p, win, r + i, c + k, strip_interior, rgb);
-          const bool live = k < npx;
-          if constexpr (EPI == EPI_STORE) {
+          float t3[3];
+          border_weight<KIDX>(r + i, c + k, p.H, p.W, t3);
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) row[3 * k + ch] = rgb[ch] * p.out_scale;
-          } else if constexpr (EPI == EPI_MINMAX) {
-            // bounds of the work-dtype image: rounding to E is monotone, so it is applied once to
-            // the reduced min / max (finalize) instead of to every pixel
-            if (live) {
-              vmin = fminf(vmin, fminf(rgb[0], fminf(rgb[1], rgb[2])));
-              vmax = fmaxf(vmax, fmaxf(rgb[0], fmaxf(rgb[1], rgb[2])));
-            }
-          } else {
-            // the reference materialises the demosaiced image in the work dtype (scale 1)
+          for (int ch = 0; ch < 3; ++ch) v[3 * k + ch] = (v[3 * k + ch] * 16.f) / (p.in_scale * t3[ch]);
+        });
+      }
+      if (p.has_ccm) {                                // bayer.py:152-153, sequential fp32 dot
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float a = v[3 * k], b = v[3 * k + 1], d = v[3 * k + 2];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch)
+            v[3 * k + ch] = (p.ccm[3 * ch] * a + p.ccm[3 * ch + 1] * b) + p.ccm[3 * ch + 2] * d;
+        }
+      }
+
+      if constexpr (EPI == EPI_MINMAX) {
+        // bounds of the work-dtype image: clamp (bayer.py:155) and rounding to E are monotone, so
+        // they are applied once to the reduced min / max (finalize) instead of to every pixel
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (fast || k < npx) {
+            vmin = fminf(vmin, fminf(v[3 * k], fminf(v[3 * k + 1], v[3 * k + 2])));
+            vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) v[j] = fminf(fmaxf(v[j], 0.f), 1.f);       // bayer.py:155
+        if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+          for (int j = 0; j < 24; ++j) v[j] *= p.out_scale;
+          store_row_dyn(p, r + i, c, v, npx);
+        } else {
+          // the reference materialises the demosaiced image in the work dtype (scale 1)
+          float row[24];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
             float t[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) t[ch] = norm01((float)cast_out<E>(rgb[ch]), lo, inv);
+            for (int ch = 0; ch < 3; ++ch) t[ch] = norm01((float)cast_out<E>(v[3 * k + ch]), lo, inv);
+            const bool live = fast || k < npx;
             if constexpr (EPI == EPI_STATS) {
               if (live) st.add(t[0], t[1], t[2]);
             } else {
@@ -440,12 +475,10 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
               }
             }
           }
-        });
-        if constexpr (EPI == EPI_STORE || EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
-      });
-    };
-    if (strip_interior && p.in_scale == 1.f) strip(std::true_type{});
-    else strip(std::false_type{});
+          if constexpr (EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
+        }
+      }
+    });
   }
 
   if (EPI == EPI_MINMAX || EPI == EPI_RH_MINMAX) {
