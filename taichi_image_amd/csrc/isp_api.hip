@@ -49,6 +49,7 @@ static int fill_common(tile::Params& p, int H, int W, int pattern, const float* 
   p.has_ccm = ccm9 != nullptr;
   for (int i = 0; i < 9; ++i) p.ccm[i] = ccm9 ? ccm9[i] : (i % 4 == 0 ? 1.f : 0.f);
   p.gamma_inv = 1.f; p.la = 1.f; p.ca = 0.f;
+  tile::set_weights(p);
   return 0;
 }
 

@@ -47,7 +47,13 @@ constexpr int LDS_COLS = TILE_W + 16;                 // image cols [c0-8, c0+TI
 constexpr int LDS_ROWS = TILE_H + 4;                  // image rows [r0-2, r0+TILE_H+2)
 constexpr int UNITS = LDS_COLS / 8;                   // 8-px load units per LDS row
 constexpr int THREADS = 256;
-constexpr int PITCH = LDS_COLS + 4;                   // LDS row pitch in floats (16-B multiple)
+// LDS row layout: the even 16-byte slots (4 columns each) of a row live in [0, HALF), the odd
+// slots in [HALF, 2*HALF).  The lanes of one ds_read_b128 / ds_write_b128 then touch consecutive
+// 16-byte slots and two strip rows are a multiple of 64 banks apart: conflict-free for the
+// hardware's 16-lane b128 groups (scratch/lds_sim.py; the linear layout cost 2.7x the cycles).
+constexpr int HALF = 80;                              // 18 slots * 4 floats + 8 pad
+constexpr int PITCH = 2 * HALF;                       // LDS row pitch in floats
+__host__ __device__ constexpr int lds_pos(int lc) { return ((lc >> 3) << 2) + (lc & 3) + ((lc >> 2) & 1) * HALF; }
 
 enum SrcKind { SRC_CFA_U8 = 0, SRC_CFA_U16 = 1, SRC_CFA_F16 = 2, SRC_CFA_F32 = 3,
                SRC_PACKED12 = 4, SRC_PACKED12_IDS = 5, SRC_PACKED16 = 6 };
@@ -71,7 +77,20 @@ struct Params {
   float out_scale;        // scale_factor of the output dtype
   float gamma_inv, la, ca;
   int debug_skip;         // measurement aid: bit 0 skips the fill, bit 1 skips the strip compute
+  // The eight distinct demosaic weights / 16, as kernel arguments on purpose: they live in SGPRs
+  // and every tap is a 4-byte v_fmac_f32 v, s, v.  As literals each FMA would carry a 32-bit
+  // constant (8 bytes) and the strip would run at the 8-byte instruction-fetch rate (~0.55x).
+  float wq[8];
 };
+
+// the distinct weight values of KW and their slot in Params::wq
+__host__ __device__ constexpr int wq_index(int w) {
+  return w == -3 ? 0 : w == -2 ? 1 : w == 1 ? 2 : w == 4 ? 3 : w == 8 ? 4 : w == 10 ? 5 : w == 12 ? 6 : 7;
+}
+constexpr int WQ_VALUES[8] = {-3, -2, 1, 4, 8, 10, 12, 16};
+static inline void set_weights(Params& p) {
+  for (int i = 0; i < 8; ++i) p.wq[i] = (float)WQ_VALUES[i] * 0.0625f;
+}
 
 // 13-tap diamond, reference order (bayer.py:15-27): (d_row, d_col)
 __device__ constexpr int8_t TAP_DR[13] = {-2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2};
@@ -132,9 +151,10 @@ MI_DEV void unpack12x8(uint32_t d0, uint32_t d1, uint32_t d2, bool ids, uint32_t
 // scaled write of packed.py:98-100, cast(f32(v) * f32(scale/4095), E), widened back to fp32
 template <class E> MI_DEV float decode_scaled(uint32_t v, float k) { return (float)cast_out<E>((float)v * k); }
 
-MI_DEV void lds_store8(float* p, const float (&v)[8]) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+// one 8-px unit (LDS columns 8*lu .. 8*lu+7) = even slot 2*lu and odd slot 2*lu+1 of the row
+MI_DEV void lds_store8(float* row, int lu, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(row + 4 * lu) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(row + HALF + 4 * lu) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -151,7 +171,7 @@ MI_DEV void fill_packed(const Params& p, float* lds, int rb, int cb) {
   for (int u = threadIdx.x; u < LDS_ROWS * UNITS; u += THREADS) {
     const int lr = u / UNITS, lu = u - lr * UNITS;
     const int r = rb + lr, c = cb + lu * 8;
-    float* dst = lds + lr * PITCH + lu * 8;
+    float* dst = lds + lr * PITCH;
     const bool inside = r >= 0 && r < p.H && c >= 0 && c < p.W;
     const int n = inside ? (c + 8 <= p.W ? 8 : p.W - c) : 0;     // W is even
     const uint8_t* rowp = base + (size_t)(inside ? r : 0) * pitch;
@@ -163,15 +183,15 @@ MI_DEV void fill_packed(const Params& p, float* lds, int rb, int cb) {
           const uint32_t w = q[3 * j] | (q[3 * j + 1] << 8) | (q[3 * j + 2] << 16);
           unpack_pair(w, ids, a, b);
         }
-        dst[2 * j] = decode_scaled<E>(a, p.k_decode);
-        dst[2 * j + 1] = decode_scaled<E>(b, p.k_decode);
+        dst[lds_pos(lu * 8 + 2 * j)] = decode_scaled<E>(a, p.k_decode);
+        dst[lds_pos(lu * 8 + 2 * j + 1)] = decode_scaled<E>(b, p.k_decode);
       }
     } else {
       const uint8_t* q = rowp + (size_t)(inside ? c : 0) * 2;
       for (int j = 0; j < 8; ++j) {
         uint32_t a = 0;
         if (j < n) a = q[2 * j] | (q[2 * j + 1] << 8);
-        dst[j] = decode_scaled<E>(a, p.k_decode);
+        dst[lds_pos(lu * 8 + j)] = decode_scaled<E>(a, p.k_decode);
       }
     }
   }
@@ -198,7 +218,7 @@ MI_DEV void fill_packed_fast(const Params& p, float* lds, int rb, int cb) {
     const int lr = (u * 3641) >> 16;                 // u / 18 for u < 16384
     const int lu = u - lr * UNITS;
     const int r = rb + lr, c = cb + lu * 8;
-    off[it] = u < NUNITS ? lr * PITCH + lu * 8 : -1;
+    off[it] = u < NUNITS ? lr * PITCH + lu * 4 : -1;
     raw[it] = make_uint4(0, 0, 0, 0);
     if (u < NUNITS && r >= 0 && r < p.H && c >= 0 && c < p.W) {
       const uint8_t* rowp = base + (size_t)r * pitch;
@@ -224,7 +244,7 @@ MI_DEV void fill_packed_fast(const Params& p, float* lds, int rb, int cb) {
     float out[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) out[i] = decode_scaled<E>(v[i], p.k_decode);
-    lds_store8(lds + off[it], out);
+    lds_store8(lds + off[it], 0, out);
   }
 }
 
@@ -241,7 +261,7 @@ MI_DEV void fill_plain(const Params& p, float* lds, int rb, int cb) {
     const int r = rb + lr, c = cb + lc;
     float v = 0.f;
     if (r >= 0 && r < p.H && c >= 0 && c < p.W) v = (float)src[(size_t)r * p.W + c];
-    lds[lr * PITCH + lc] = v;
+    lds[lr * PITCH + lds_pos(lc)] = v;
   }
 }
 
@@ -265,12 +285,19 @@ MI_DEV void fill_tile(const Params& p, float* lds, int rb, int cb) {
 MI_DEV void load_window(const float* lds, int tx, int ty, float (&win)[6][12]) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    const float* rp = lds + (2 * ty + k) * PITCH + 8 * tx + 6;
-    const float2 a = *reinterpret_cast<const float2*>(rp);
-    const float4 b = *reinterpret_cast<const float4*>(rp + 2);
-    const float4 c = *reinterpret_cast<const float4*>(rp + 6);
-    const float2 d = *reinterpret_cast<const float2*>(rp + 10);
-    win[k][0] = a.x; win[k][1] = a.y;
+    // window col j <-> LDS col 8*tx + 6 + j: slots 2tx+1 (upper half), 2tx+2, 2tx+3, 2tx+4 (lower half)
+    // volatile: keeps hipcc from narrowing / re-pairing these into ds_read2_b64 / ds_read2_b32,
+    // whose 32-bank addressing conflicts on this layout; each stays one conflict-free ds_read_b128
+    // (the pointer is cast back to the LDS address space: a volatile access through a generic
+    // pointer would become flat_load)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const volatile __attribute__((address_space(3))) f4* lds_f4_ptr;
+    const float* rp = lds + (2 * ty + k) * PITCH + 4 * tx;
+    const f4 a = *(lds_f4_ptr)(rp + HALF);
+    const f4 b = *(lds_f4_ptr)(rp + 4);
+    const f4 c = *(lds_f4_ptr)(rp + HALF + 4);
+    const f4 d = *(lds_f4_ptr)(rp + 8);
+    win[k][0] = a.z; win[k][1] = a.w;
     win[k][2] = b.x; win[k][3] = b.y; win[k][4] = b.z; win[k][5] = b.w;
     win[k][6] = c.x; win[k][7] = c.y; win[k][8] = c.z; win[k][9] = c.w;
     win[k][10] = d.x; win[k][11] = d.y;
@@ -280,17 +307,18 @@ MI_DEV void load_window(const float* lds, int tx, int ty, float (&win)[6][12]) {
 // filter_at (bayer.py:138-155) for the pixel at strip position (I, K): sequential fp32 accumulation
 // over the non-zero taps in reference order with the weights w/16.
 template <int KIDX, bool EXACT, int I, int K>
-MI_DEV void accumulate(const float (&win)[6][12], float (&acc)[3]) {
-  acc[0] = acc[1] = acc[2] = 0.f;
+MI_DEV void accumulate(const float (&wq)[8], const float (&win)[6][12], float (&acc)[3]) {
+  bool first[3] = {true, true, true};
   static_for<0, 13>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     const float x = win[I + 2 + TAP_DR[t]][K + 2 + TAP_DC[t]];
     static_for<0, 3>([&](auto cc) {
       constexpr int ch = decltype(cc)::value;
       constexpr int wi = KW[KIDX][t][ch];
-      constexpr float w = (float)wi * 0.0625f;
       if constexpr (wi != 0) {
-        if constexpr (EXACT) acc[ch] = __builtin_fmaf(x, w, acc[ch]);
+        const float w = wq[wq_index(wi)];
+        if (first[ch]) { acc[ch] = x * w; first[ch] = false; }      // == fma(x, w, +0)
+        else if constexpr (EXACT) acc[ch] = __builtin_fmaf(x, w, acc[ch]);
         else acc[ch] = acc[ch] + x * w;
       }
     });
@@ -368,8 +396,14 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * PITCH];
   __shared__ float red[4][8];
 
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8).  With a row-major tile order
+  // and tiles_x % 8 == 0 every left-edge tile would land on one XCD and every right-edge tile on
+  // another, and the edge tiles are the slow ones (border renormalisation).  Rotating each tile row
+  // by its row index spreads them over all XCDs (speed only; any mapping is correct).
   const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
-  const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+  const int by = blockIdx.x / tiles_x;
+  int bx = blockIdx.x - by * tiles_x + by % tiles_x;
+  if (bx >= tiles_x) bx -= tiles_x;
   const int r0 = by * TILE_H, c0 = bx * TILE_W;
 
   if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
@@ -399,27 +433,45 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
     load_window(lds, tx, ty, win);
     // every tap of all 16 pixels in bounds, and c / (in_scale * t) == c / 16 ?
     const bool fast = p.in_scale == 1.f && r >= 2 && r + 1 < p.H - 2 && c >= 2 && c + 7 < p.W - 2;
+    // Wave-uniform predicates (scalar branches): the slow blocks below are real branches that
+    // interior waves skip, not per-lane selects the compiler would flatten into the fast stream.
+    const bool wave_has_slow = __builtin_amdgcn_ballot_w64(!fast) != 0 && !(p.debug_skip & 16);
+    const bool wave_all_full = __builtin_amdgcn_ballot_w64(npx != 8) == 0;
 
     static_for<0, 2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       float v[24];                                    // the row's 8 px x RGB, normalised
+      if (p.debug_skip & 8) {                       // measurement aid: no accumulation
+#pragma unroll
+        for (int j = 0; j < 24; ++j) v[j] = win[i + 2][(j % 12)] + win[i + (j & 3)][j >> 1];
+      } else {
       static_for<0, 8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
         float acc[3];
-        accumulate<KIDX, EXACT, i, k>(win, acc);
+        accumulate<KIDX, EXACT, i, k>(p.wq, win, acc);
         v[3 * k] = acc[0]; v[3 * k + 1] = acc[1]; v[3 * k + 2] = acc[2];
       });
-      if (!fast) {
-        // border strips / CFAs with scale != 1: c / (in_scale * t), correctly rounded, with
-        // c == acc * 16 exactly and t the in-bounds weight sum (16 when every tap is in bounds)
+      }
+      if (wave_has_slow) {
+        // border pixels / CFAs with scale != 1: c / (in_scale * t), correctly rounded, with
+        // c == acc * 16 exactly and t the in-bounds weight sum (16 when every tap is in bounds).
+        // Each pixel position is skipped (scalar branch) when no lane of the wave needs it, e.g.
+        // only columns 0-1 of a left-edge strip are border pixels.
         static_for<0, 8>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
-          float t3[3];
-          border_weight<KIDX>(r + i, c + k, p.H, p.W, t3);
+          const int rr = r + i, cc = c + k;
+          const bool need = p.in_scale != 1.f || rr < 2 || rr >= p.H - 2 || cc < 2 || cc >= p.W - 2;
+          if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            float t3[3];
+            border_weight<KIDX>(rr, cc, p.H, p.W, t3);
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) v[3 * k + ch] = (v[3 * k + ch] * 16.f) / (p.in_scale * t3[ch]);
+            for (int ch = 0; ch < 3; ++ch) {
+              const float fixed = (v[3 * k + ch] * 16.f) / (p.in_scale * t3[ch]);
+              v[3 * k + ch] = need ? fixed : v[3 * k + ch];
+            }
+          }
         });
       }
       if (p.has_ccm) {                                // bayer.py:152-153, sequential fp32 dot
@@ -432,55 +484,65 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
         }
       }
 
-      if constexpr (EPI == EPI_MINMAX) {
-        // bounds of the work-dtype image: clamp (bayer.py:155) and rounding to E are monotone, so
-        // they are applied once to the reduced min / max (finalize) instead of to every pixel
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (fast || k < npx) {
-            vmin = fminf(vmin, fminf(v[3 * k], fminf(v[3 * k + 1], v[3 * k + 2])));
-            vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 24; ++j) v[j] = fminf(fmaxf(v[j], 0.f), 1.f);       // bayer.py:155
-        if constexpr (EPI == EPI_STORE) {
-#pragma unroll
-          for (int j = 0; j < 24; ++j) v[j] *= p.out_scale;
-          store_row_dyn(p, r + i, c, v, npx);
-        } else {
-          // the reference materialises the demosaiced image in the work dtype (scale 1)
-          float row[24];
+      // the row epilogue, specialised on "all 8 pixels of every lane are live" (scalar branch)
+      auto epilogue = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        if constexpr (EPI == EPI_MINMAX) {
+          // bounds of the work-dtype image: clamp (bayer.py:155) and rounding to E are monotone,
+          // so they are applied once to the reduced min / max (finalize), not to every pixel
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            float t[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) t[ch] = norm01((float)cast_out<E>(v[3 * k + ch]), lo, inv);
-            const bool live = fast || k < npx;
-            if constexpr (EPI == EPI_STATS) {
-              if (live) st.add(t[0], t[1], t[2]);
-            } else {
-              float q[3];
-              reinhard_px(t, rk, q);
-              if constexpr (EPI == EPI_RH_MINMAX) {
-                if (live) {
-                  vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
-                  vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
-                }
-              } else {
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                  row[3 * k + ch] = linear_px(q[ch], lo2, inv2, p.gamma_inv, p.out_scale);
-              }
+            if (FULL || k < npx) {
+              vmin = fminf(vmin, fminf(v[3 * k], fminf(v[3 * k + 1], v[3 * k + 2])));
+              vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
             }
           }
-          if constexpr (EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 24; ++j) v[j] = fminf(fmaxf(v[j], 0.f), 1.f);       // bayer.py:155
+          if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+            for (int j = 0; j < 24; ++j) v[j] *= p.out_scale;
+            store_row_dyn(p, r + i, c, v, npx);
+          } else {
+            // the reference materialises the demosaiced image in the work dtype (scale 1)
+            float row[24];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float t[3];
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) t[ch] = norm01((float)cast_out<E>(v[3 * k + ch]), lo, inv);
+              const bool live = FULL || k < npx;
+              if constexpr (EPI == EPI_STATS) {
+                if (live) st.add(t[0], t[1], t[2]);
+              } else {
+                float q[3];
+                reinhard_px(t, rk, q);
+                if constexpr (EPI == EPI_RH_MINMAX) {
+                  if (live) {
+                    vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
+                    vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
+                  }
+                } else {
+#pragma unroll
+                  for (int ch = 0; ch < 3; ++ch)
+                    row[3 * k + ch] = linear_px(q[ch], lo2, inv2, p.gamma_inv, p.out_scale);
+                }
+              }
+            }
+            if constexpr (EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
+          }
         }
-      }
+      };
+      if (wave_all_full) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
     });
   }
 
+  if (p.debug_skip & 4) {                       // measurement aid: no block reduction
+    if (vmin + vmax + st.slog == 12345.f) p.partials[blockIdx.x] = vmin;
+    return;
+  }
   if (EPI == EPI_MINMAX || EPI == EPI_RH_MINMAX) {
     const float v[2] = {vmin, vmax};
     const int op[2] = {0, 1};
