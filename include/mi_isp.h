@@ -156,6 +156,13 @@ int mi_isp_pipeline12_pass(const uint8_t* packed_dev, void* out_dev, int H, int 
                            float gamma, float light_adapt, float color_adapt, int pass,
                            void* ws_dev, void* stream);
 
+/* Events around the dominant kernel (the final map + store pass) of every following
+ * mi_isp_pipeline12_reinhard[_batch] frame, recorded on the stream the kernel runs on.
+ * enable(n): time up to n launches (0 = off).  collect(): waits for the recorded events and
+ * returns their average duration in microseconds and their number. */
+int mi_isp_profile_enable(int max_launches);
+int mi_isp_profile_collect(float* avg_us, int* count);
+
 #ifdef __cplusplus
 }
 #endif

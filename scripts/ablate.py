@@ -25,4 +25,4 @@ def t(code, reps=50):
     return e0.elapsed_time(e1) * 1e3 / reps
 for p in (0, 1, 3):
     print(f"pass {p}: full {t(p):.1f} us | no fill {t(p + 16):.1f} | no compute {t(p + 32):.1f} | neither {t(p + 48):.1f}"
-          f" | no reduce {t(p + 64):.1f} | no fill+no reduce {t(p + 16 + 64):.1f} | no fill,reduce,accumulate {t(p + 16 + 64 + 128):.1f} | +no fixup {t(p + 16 + 64 + 128 + 256):.1f} | only no fixup {t(p + 256):.1f}")
+          f" | no reduce {t(p + 64):.1f} | no fill+no reduce {t(p + 16 + 64):.1f} | no fill,reduce,accumulate {t(p + 16 + 64 + 128):.1f} | +no fixup {t(p + 16 + 64 + 128 + 256):.1f} | only no fixup {t(p + 256):.1f} | no store {t(p + 512):.1f}")

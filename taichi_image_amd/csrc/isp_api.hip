@@ -102,6 +102,44 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
   return tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream);
 }
 
+// ---- measurement aid: HIP events around the dominant kernel, on the stream it runs on -----------------
+#include <vector>
+static struct {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+} g_prof;
+
+extern "C" int mi_isp_profile_enable(int max_launches) {
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.used = 0;
+  g_prof.on = max_launches > 0;
+  for (int i = 0; i < 2 * max_launches; ++i) {
+    hipEvent_t e;
+    MI_HIP(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  return 0;
+}
+
+extern "C" int mi_isp_profile_collect(float* avg_us, int* count) {
+  MI_REQUIRE(avg_us && count, "profile_collect: null pointer");
+  double sum = 0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    float ms = 0.f;
+    MI_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+    MI_HIP(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+    sum += ms * 1e3;
+    ++n;
+  }
+  *avg_us = n ? (float)(sum / n) : 0.f;
+  *count = n;
+  g_prof.used = 0;
+  return 0;
+}
+
 // One frame of the fused config-2 chain: four tile passes + three finalize launches.
 static int pipeline_frame(tile::Params p, int pattern, int work_dtype, float intensity, float* ws, hipStream_t s) {
   float* fp = ws;
@@ -119,7 +157,14 @@ static int pipeline_frame(tile::Params p, int pattern, int work_dtype, float int
   if (int rc = ew::finalize(ew::FIN_STATS, fa, s)) return rc;
   if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_RH_MINMAX, s)) return rc;   // :150,153
   if (int rc = ew::finalize(ew::FIN_BOUNDS2, fa, s)) return rc;
-  return tile::launch(p, work_dtype, pattern, tile::EPI_RH_STORE, s);                      // :154
+  const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (timed) MI_HIP(hipEventRecord(g_prof.ev[g_prof.used], s));
+  const int rc = tile::launch(p, work_dtype, pattern, tile::EPI_RH_STORE, s);              // :154
+  if (timed) {
+    MI_HIP(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
+    g_prof.used += 2;
+  }
+  return rc;
 }
 
 static int pipeline_params(tile::Params& p, int H, int W, int ids_format, int pattern, const float* ccm9,

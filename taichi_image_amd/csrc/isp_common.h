@@ -69,21 +69,25 @@ template <> struct ScaleOf<uint16_t> { static constexpr float value = 65535.f; }
 MI_DEV float nmin(float a, float b) { return fminf(a, b); }
 MI_DEV float nmax(float a, float b) { return fmaxf(a, b); }
 
-MI_DEV float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+// Wave64 reductions without LDS traffic: four DPP steps fold each row of 16 lanes (the DPP
+// operand rides on the min/max/add itself), then two cross-row exchanges.  ds_bpermute-based
+// shuffles cost a dependent LDS round trip per step (12-42 of them per block here).
+template <int CTRL> MI_DEV float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-MI_DEV float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-MI_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+#define MI_ROW_REDUCE(OP)                      \
+  v = OP(v, dpp_mov<0xB1>(v));                 \
+  v = OP(v, dpp_mov<0x4E>(v));                 \
+  v = OP(v, dpp_mov<0x141>(v));                \
+  v = OP(v, dpp_mov<0x140>(v));                \
+  v = OP(v, __shfl_xor(v, 16, 64));            \
+  v = OP(v, __shfl_xor(v, 32, 64));
+MI_DEV float op_add(float a, float b) { return a + b; }
+MI_DEV float wave_min(float v) { MI_ROW_REDUCE(fminf) return v; }
+MI_DEV float wave_max(float v) { MI_ROW_REDUCE(fmaxf) return v; }
+MI_DEV float wave_sum(float v) { MI_ROW_REDUCE(op_add) return v; }
+#undef MI_ROW_REDUCE
 
 // Block reduction of up to 8 values per thread for 256-thread blocks (4 waves): each wave
 // shuffles down to one value, the per-wave results meet in LDS, thread k < NV combines them

@@ -350,23 +350,20 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
         }
       } else if (MODE == PM_LINEAR_STORE) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = linear_px(x[ch], lo, inv, a.gamma_inv, a.out_scale);
+        for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = x[ch];
       } else if (MODE == PM_ISP_RH_P1) {
         // camera_isp.py:200: no clamp on the normalised value here
         float t[3], q[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) t[ch] = (x[ch] - lo) * inv;
-        reinhard_px(t, rk, q);
+        if (rk.ca == 0.f) reinhard_px<true>(t, rk, q);
+        else reinhard_px<false>(t, rk, q);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = q[ch];
         if (live) vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
       } else if (MODE == PM_ISP_RH_P2) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float q = x[ch] * maxout_inv;
-          if (a.gamma_inv != 1.f) q = hw_pow(q, a.gamma_inv);
-          o[3 * k + ch] = 255.f * q;
-        }
+        for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = x[ch] * maxout_inv;
       } else {
         float t[3];
 #pragma unroll
@@ -375,7 +372,8 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
           if (live) st.add(t[0], t[1], t[2]);
         } else {
           float q[3];
-          reinhard_px(t, rk, q);
+          if (rk.ca == 0.f) reinhard_px<true>(t, rk, q);
+          else reinhard_px<false>(t, rk, q);
           if (MODE == PM_RH_MINMAX) {
             if (live) {
               vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
@@ -383,11 +381,22 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
             }
           } else {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = linear_px(q[ch], lo2, inv2, a.gamma_inv, a.out_scale);
+            for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = q[ch];
           }
         }
       }
     }
+    if (MODE == PM_ISP_RH_P2) {                      // camera_isp.py:217-218 (no clamp there)
+      if (a.gamma_inv != 1.f) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 24; ++j) o[j] = hw_pow(o[j], a.gamma_inv);
+      }
+#pragma unroll
+      for (int j = 0; j < 24; ++j) o[j] *= 255.f;
+    }
+    if (MODE == PM_LINEAR_STORE) linear_n<24>(o, lo, inv, a.gamma_inv, a.out_scale);
+    if (MODE == PM_RH_STORE) linear_n<24>(o, lo2, inv2, a.gamma_inv, a.out_scale);
     if (MODE == PM_ISP_RH_P1) {
       store24<TI>(static_cast<TI*>(a.inplace) + px0 * 3, o, npx, a.vec_in);
     } else if (MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2) {
@@ -481,34 +490,42 @@ __global__ __launch_bounds__(EW_THREADS) void metering_kernel(const ew::PtrList 
 // finalize: one block folds the per-block partials (sums in fp64) and thread 0 derives the
 // scalars of the next pass with the accurate libm-grade functions.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EW_THREADS) void finalize_kernel(int mode, const ew::FinArgs a) {
-  __shared__ double sh[7][EW_THREADS / 64];
+constexpr int FIN_THREADS = 1024;
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(int mode, const ew::FinArgs a) {
+  __shared__ double sh[7][FIN_THREADS / 64];
   __shared__ double tot[7];
   const int nrows = (mode == ew::FIN_STATS || mode == ew::FIN_ISP_STATS || mode == ew::FIN_ISP_SUMS) ? 7 : 2;
-  for (int k = 0; k < nrows; ++k) {
-    const int op = k == 0 ? 0 : (k == 1 ? 1 : 2);
-    double acc = op == 0 ? (double)__builtin_inff() : (op == 1 ? -(double)__builtin_inff() : 0.0);
-    for (int i = threadIdx.x; i < a.nblocks; i += blockDim.x) {
-      const double v = (double)a.partials[(size_t)k * a.stride + i];
-      if (op == 0) acc = fmin(acc, v);
-      else if (op == 1) acc = fmax(acc, v);
-      else acc += v;
-    }
+  // row 0: min, row 1: max, rows 2..6: sums (fp64).  All rows of an index are loaded together so the
+  // (at most 4) iterations carry independent loads instead of one dependent latency per row.
+  double acc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc[k] = k == 0 ? (double)__builtin_inff() : (k == 1 ? -(double)__builtin_inff() : 0.0);
+  for (int i = threadIdx.x; i < a.nblocks; i += FIN_THREADS) {
+    float v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = k < nrows ? a.partials[(size_t)k * a.stride + i] : 0.f;
+    acc[0] = fmin(acc[0], (double)v[0]);
+    acc[1] = fmax(acc[1], (double)v[1]);
+#pragma unroll
+    for (int k = 2; k < 7; ++k) acc[k] += (double)v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    if (k >= nrows) break;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const double other = __shfl_xor(acc, o, 64);
-      acc = op == 0 ? fmin(acc, other) : (op == 1 ? fmax(acc, other) : acc + other);
+      const double other = __shfl_xor(acc[k], o, 64);
+      acc[k] = k == 0 ? fmin(acc[k], other) : (k == 1 ? fmax(acc[k], other) : acc[k] + other);
     }
-    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = acc[k];
   }
   __syncthreads();
   if (threadIdx.x < nrows) {
     const int k = threadIdx.x;
-    const int op = k == 0 ? 0 : (k == 1 ? 1 : 2);
-    double acc = sh[k][0];
-    for (int w = 1; w < EW_THREADS / 64; ++w)
-      acc = op == 0 ? fmin(acc, sh[k][w]) : (op == 1 ? fmax(acc, sh[k][w]) : acc + sh[k][w]);
-    tot[k] = acc;
+    double r = sh[k][0];
+    for (int w = 1; w < FIN_THREADS / 64; ++w)
+      r = k == 0 ? fmin(r, sh[k][w]) : (k == 1 ? fmax(r, sh[k][w]) : r + sh[k][w]);
+    tot[k] = r;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -593,7 +610,7 @@ __global__ void isp_reinhard_prep_kernel(const float* state9, float* fp, float i
 namespace ew {
 
 int finalize(int mode, const FinArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(EW_THREADS), 0, s, mode, a);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, mode, a);
   MI_LAUNCH_CHECK();
   return 0;
 }

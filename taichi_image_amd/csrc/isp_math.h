@@ -17,8 +17,11 @@ MI_DEV float hw_log(float x) { return hw_log2(x) * 0.6931471805599453f; }
 // color/__init__.py:7-10
 MI_DEV float rgb_gray(float r, float g, float b) { return (r * 0.299f + g * 0.587f) + b * 0.114f; }
 
+// clamp to [0, 1] in one instruction (v_med3_f32; a NaN input yields min3 of the others = 0)
+MI_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
+
 // tonemap.py:12-17 with gamma == 1 (linear_func into the f32 temp): clamp((x-lo)*inv, 0, 1)
-MI_DEV float norm01(float x, float lo, float inv) { return fminf(fmaxf((x - lo) * inv, 0.f), 1.f); }
+MI_DEV float norm01(float x, float lo, float inv) { return clamp01((x - lo) * inv); }
 
 // Running statistics of tonemap.py:78-103 / camera_isp.py:117-128.  min/max are taken on
 // max(gray, 1e-4) and the (monotone) log is applied once when the partials are combined.
@@ -42,11 +45,13 @@ struct ReinhardK {
 };
 
 // reinhard_func (tonemap.py:120-131) / camera_isp.py:200-210 on an already normalised pixel.
+// CA0 (color_adapt == 0): adapt_color == gray and mean3 is the same for the three channels, so
+// the three channels share one pow.  A template parameter, not a per-pixel test: the callers branch
+// once per row of pixels (a scalar branch), keeping the pixel code straight-line.
+template <bool CA0>
 MI_DEV void reinhard_px(const float (&t)[3], const ReinhardK& k, float (&out)[3]) {
   const float g = rgb_gray(t[0], t[1], t[2]);
-  if (k.ca == 0.f) {
-    // color_adapt == 0: adapt_color == gray and mean3 is the same for the three channels,
-    // so the three channels share one pow.
+  if constexpr (CA0) {
     const float am = k.mean3[0] + k.la * (g - k.mean3[0]);
     const float ad = hw_pow(k.ei * am, k.map_key);
 #pragma unroll
@@ -68,6 +73,23 @@ MI_DEV float linear_px(float x, float lo, float inv, float gamma_inv, float scal
   float v = (x - lo) * inv;
   if (gamma_inv != 1.f) v = hw_pow(v, gamma_inv);
   return fminf(fmaxf(v, 0.f), 1.f) * scale;
+}
+
+// The same for N values with ONE scalar branch on gamma.  Written per value, hipcc if-converts the
+// branch into select(pow(v), v): a v_log + v_exp (quarter-rate) per value even when gamma == 1.
+// The empty volatile asm makes the pow block non-speculatable, so it stays a real branch.
+template <int N>
+MI_DEV void linear_n(float (&v)[N], float lo, float inv, float gamma_inv, float scale) {
+  if (gamma_inv != 1.f) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = clamp01(hw_pow((v[i] - lo) * inv, gamma_inv)) * scale;
+  } else {
+    // gamma == 1: clamp(x, 0, 1) * scale == med3(x * scale, 0, scale) up to one rounding
+    const float inv_s = inv * scale;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_fmed3f((v[i] - lo) * inv_s, 0.f, scale);
+  }
 }
 
 #pragma clang fp contract(off)

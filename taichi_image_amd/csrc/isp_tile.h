@@ -376,6 +376,13 @@ MI_DEV void store_row(T* dst, const float (&v)[24], int npx, bool vec) {
 }
 
 MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], int npx) {
+  if (p.debug_skip & 32) {                      // measurement aid: no global stores
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) s += v[i];
+    if (s == 12345.678f) static_cast<float*>(p.dst)[0] = s;
+    return;
+  }
   const size_t off = ((size_t)r * p.W + c) * 3;
   switch (p.out_dtype) {
     case MI_U8: store_row<uint8_t>(static_cast<uint8_t*>(p.dst) + off, v, npx, p.vec_store); break;
@@ -400,10 +407,14 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
   // and tiles_x % 8 == 0 every left-edge tile would land on one XCD and every right-edge tile on
   // another, and the edge tiles are the slow ones (border renormalisation).  Rotating each tile row
   // by its row index spreads them over all XCDs (speed only; any mapping is correct).
-  const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
-  const int by = blockIdx.x / tiles_x;
-  int bx = blockIdx.x - by * tiles_x + by % tiles_x;
+  // The tile rows are also rotated by half the image so that the (slow) top and bottom rows run in
+  // the middle of the grid instead of being its tail.
+  const int tiles_x = (p.W + TILE_W - 1) / TILE_W, tiles_y = (p.H + TILE_H - 1) / TILE_H;
+  const int gy = blockIdx.x / tiles_x;
+  int bx = blockIdx.x - gy * tiles_x + gy % tiles_x;
   if (bx >= tiles_x) bx -= tiles_x;
+  int by = gy + tiles_y / 2;
+  if (by >= tiles_y) by -= tiles_y;
   const int r0 = by * TILE_H, c0 = bx * TILE_W;
 
   if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
@@ -485,8 +496,9 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
       }
 
       // the row epilogue, specialised on "all 8 pixels of every lane are live" (scalar branch)
-      auto epilogue = [&](auto full_c) {
+      auto epilogue = [&](auto full_c, auto ca0_c) {
         constexpr bool FULL = decltype(full_c)::value;
+        constexpr bool CA0 = decltype(ca0_c)::value;
         if constexpr (EPI == EPI_MINMAX) {
           // bounds of the work-dtype image: clamp (bayer.py:155) and rounding to E are monotone,
           // so they are applied once to the reduced min / max (finalize), not to every pixel
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
           }
         } else {
 #pragma unroll
-          for (int j = 0; j < 24; ++j) v[j] = fminf(fmaxf(v[j], 0.f), 1.f);       // bayer.py:155
+          for (int j = 0; j < 24; ++j) v[j] = clamp01(v[j]);                       // bayer.py:155
           if constexpr (EPI == EPI_STORE) {
 #pragma unroll
             for (int j = 0; j < 24; ++j) v[j] *= p.out_scale;
@@ -517,7 +529,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
                 if (live) st.add(t[0], t[1], t[2]);
               } else {
                 float q[3];
-                reinhard_px(t, rk, q);
+                reinhard_px<CA0>(t, rk, q);
                 if constexpr (EPI == EPI_RH_MINMAX) {
                   if (live) {
                     vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
@@ -525,17 +537,25 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
                   }
                 } else {
 #pragma unroll
-                  for (int ch = 0; ch < 3; ++ch)
-                    row[3 * k + ch] = linear_px(q[ch], lo2, inv2, p.gamma_inv, p.out_scale);
+                  for (int ch = 0; ch < 3; ++ch) row[3 * k + ch] = q[ch];
                 }
               }
             }
-            if constexpr (EPI == EPI_RH_STORE) store_row_dyn(p, r + i, c, row, npx);
+            if constexpr (EPI == EPI_RH_STORE) {
+              linear_n<24>(row, lo2, inv2, p.gamma_inv, p.out_scale);                 // tonemap.py:154
+              store_row_dyn(p, r + i, c, row, npx);
+            }
           }
         }
       };
-      if (wave_all_full) epilogue(std::true_type{});
-      else epilogue(std::false_type{});
+      if constexpr (EPI == EPI_RH_MINMAX || EPI == EPI_RH_STORE) {
+        if (wave_all_full && rk.ca == 0.f) epilogue(std::true_type{}, std::true_type{});      // the hot path
+        else if (rk.ca == 0.f) epilogue(std::false_type{}, std::true_type{});
+        else epilogue(std::false_type{}, std::false_type{});
+      } else {
+        if (wave_all_full) epilogue(std::true_type{}, std::true_type{});
+        else epilogue(std::false_type{}, std::true_type{});
+      }
     });
   }
 

@@ -305,6 +305,20 @@ def test_pipeline12_matches_unfused_chain_4k(ti, dev):
     assert float(fused.float().min()) == 0.0 and float(fused.float().max()) == 1.0
 
 
+def test_pipeline12_4k_against_c_oracle(ti, dev):
+    """Full BASELINE size against the CPU oracle (the C/OpenMP restatement, ~1 s per frame)."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/liborc_isp.so not built")
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    from taichi_image_amd.synthetic import synthetic_packed12
+    packed = synthetic_packed12(3)
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev)).cpu().numpy()
+    assert_close(got, c_oracle.pipeline12_reinhard(packed), "pipeline12 4K vs C oracle")
+    got8 = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=ti.types.u8, gamma=0.6).cpu().numpy()
+    assert_close(got8, c_oracle.pipeline12_reinhard(packed, out="u8", gamma=0.6), "pipeline12 4K u8 vs C oracle")
+
+
 def test_batch_pipeline_equals_single(ti, rng, dev):
     from taichi_image_amd.pipeline import BatchPipeline, pipeline12_reinhard
     H, W = 64, 128
