@@ -113,7 +113,7 @@ def workspace(H: int, W: int, device: torch.device, slots: int = 1) -> torch.Ten
     if ws is None:
         if len(_ws_cache) > 64:
             _ws_cache.clear()
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # arrival counters start at 0
         _ws_cache[key] = ws
     return ws
 

@@ -1,0 +1,95 @@
+// Finalize step shared by finalize_kernel (isp_elementwise.hip) and the last-arriver block of the
+// persistent tile kernel (isp_tile.h): turns the reduced partials into the scalars of the next pass.
+#pragma once
+#include "isp_common.h"
+
+namespace ew {
+
+// finalize modes: combine per-block partials into FrameParams / the ISP state
+enum FinMode {
+  FIN_BOUNDS = 0,      // partial rows {min,max}            -> FP_LO, FP_HI, FP_INV
+  FIN_STATS = 1,       // rows {gmin,gmax,slog2,sgray,s0,s1,s2}, n px -> stateless metering + Reinhard scalars
+  FIN_BOUNDS2 = 2,     // {min,max}                          -> FP_LO2, FP_HI2, FP_INV2
+  FIN_MAXOUT = 3,      // {-,max}                            -> FP_MAXOUT = max(1e-6, max)
+  FIN_ISP_BOUNDS = 4,  // {min,max} + state9, alpha          -> FP_LO/FP_HI = blended bounds (+raw to out)
+  FIN_ISP_STATS = 5,   // 7 rows + blended bounds + state9   -> state9 updated (camera_isp.py:164-166)
+  FIN_ISP_SUMS = 6,    // 7 rows                             -> out8 = [lmin,lmax,sum_log,sum_gray,sr,sg,sb,n]
+  FIN_RAW_BOUNDS = 7   // {min,max}                          -> out2 raw
+};
+
+struct FinArgs {
+  const float* partials; int stride; int nblocks;
+  float* fp;            // FrameParams
+  float* state9;        // ISP state (in/out) or NULL
+  const float* bounds_in;  // FIN_ISP_SUMS/FIN_ISP_STATS: blended bounds (device) or NULL -> fp
+  float* out;           // raw outputs (FIN_ISP_SUMS, FIN_RAW_BOUNDS)
+  float n_px;           // pixel count for the means
+  float alpha;          // ISP lerp weight
+  float intensity, la, ca;
+  int bounds_post;      // FIN_BOUNDS: 0 = bounds are final; 1 = clamp to [0,1]; 2 = clamp, then round to f16
+};
+
+// tot: row 0 = min, row 1 = max, rows 2..6 = sums (fp64) over all blocks.  One thread runs this.
+MI_DEV void finalize_scalars(int mode, const FinArgs& a, const double* tot) {
+  float lo = (float)tot[0], hi = (float)tot[1];
+  if (mode == FIN_BOUNDS && a.bounds_post > 0) {
+    // tile bounds pass: reduced before the clamp / work-dtype rounding of bayer.py:155,134
+    lo = fminf(fmaxf(lo, 0.f), 1.f); hi = fminf(fmaxf(hi, 0.f), 1.f);
+    if (a.bounds_post > 1) { lo = (float)(half_t)lo; hi = (float)(half_t)hi; }
+  }
+  float* fp = a.fp;
+  switch (mode) {
+    case FIN_BOUNDS:
+      fp[FP_LO] = lo; fp[FP_HI] = hi; fp[FP_INV] = 1.0f / (hi - lo);   // tonemap.py:13
+      break;
+    case FIN_BOUNDS2:
+      fp[FP_LO2] = lo; fp[FP_HI2] = hi; fp[FP_INV2] = 1.0f / (hi - lo);
+      break;
+    case FIN_MAXOUT:
+      fp[FP_MAXOUT] = fmaxf(1e-6f, hi);                               // camera_isp.py:190,213
+      break;
+    case FIN_RAW_BOUNDS:
+      a.out[0] = lo; a.out[1] = hi;
+      break;
+    case FIN_ISP_BOUNDS: {
+      // camera_isp.py:156-157: b = lerp(alpha, new, prev) = new + alpha * (prev - new)
+      const float pmin = a.state9[0], pmax = a.state9[1];
+      fp[FP_LO] = lo + a.alpha * (pmin - lo);
+      fp[FP_HI] = hi + a.alpha * (pmax - hi);
+      break;
+    }
+    default: {
+      const float LN2 = 0.6931471805599453f;
+      const float lmin = logf(lo), lmax = logf(hi);      // lo/hi here are min/max of max(gray,1e-4)
+      const float slog = (float)(tot[2] * 0.6931471805599453);
+      const float sgray = (float)tot[3];
+      const float s0 = (float)tot[4], s1 = (float)tot[5], s2 = (float)tot[6];
+      (void)LN2;
+      if (mode == FIN_ISP_SUMS) {
+        a.out[0] = lmin; a.out[1] = lmax; a.out[2] = slog; a.out[3] = sgray;
+        a.out[4] = s0; a.out[5] = s1; a.out[6] = s2; a.out[7] = a.n_px;
+      } else if (mode == FIN_ISP_STATS) {
+        // camera_isp.py:131-134,164-166
+        const float n = a.n_px;
+        const float* b = a.bounds_in ? a.bounds_in : fp + FP_LO;
+        const float v[9] = {b[0], b[1], lmin, lmax, slog / n, sgray / n, s0 / n, s1 / n, s2 / n};
+        for (int i = 0; i < 9; ++i) a.state9[i] = v[i] + a.alpha * (a.state9[i] - v[i]);
+      } else {
+        // tonemap.py:99-103 (log_bounds = (lmin, -lmax): reference sign quirk), :115-119
+        const float n = a.n_px;
+        const float Bmin = lmin, Bmax = -lmax;
+        const float lmean = slog / n, gmean = sgray / n;
+        const float rm[3] = {s0 / n, s1 / n, s2 / n};
+        const float key = (Bmax - lmean) / (Bmax - Bmin);
+        fp[FP_BMIN] = Bmin; fp[FP_BMAX] = Bmax; fp[FP_LMEAN] = lmean; fp[FP_GMEAN] = gmean;
+        fp[FP_RMEAN] = rm[0]; fp[FP_RMEAN + 1] = rm[1]; fp[FP_RMEAN + 2] = rm[2];
+        fp[FP_MAPKEY] = 0.3f + 0.7f * powf(key, 1.4f);
+        fp[FP_EI] = expf(-a.intensity);
+        for (int c = 0; c < 3; ++c) fp[FP_MEAN3 + c] = gmean + a.ca * (rm[c] - gmean);
+      }
+      break;
+    }
+  }
+}
+
+}  // namespace ew

@@ -56,7 +56,7 @@ class BatchPipeline:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
         self.stream_ptrs = (_native.c_void_p * len(self.streams))(*[s.cuda_stream for s in self.streams])
         ws_bytes = int(_native.lib().mi_isp_workspace_bytes(H, W))
-        self.ws = torch.empty(ws_bytes * n_frames, dtype=torch.uint8, device=device)
+        self.ws = torch.zeros(ws_bytes * n_frames, dtype=torch.uint8, device=device)
         self.outputs = [torch.empty((H, W, 3), dtype=self.odt.torch, device=device) for _ in range(n_frames)]
         self.out_ptrs = _native.ptr_array(self.outputs)
 
