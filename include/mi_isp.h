@@ -156,12 +156,12 @@ int mi_isp_pipeline12_pass(const uint8_t* packed_dev, void* out_dev, int H, int 
                            float gamma, float light_adapt, float color_adapt, int pass,
                            void* ws_dev, void* stream);
 
-/* Events around the dominant kernel (the final map + store pass) of every following
- * mi_isp_pipeline12_reinhard[_batch] frame, recorded on the stream the kernel runs on.
- * enable(n): time up to n launches (0 = off).  collect(): waits for the recorded events and
- * returns their average duration in microseconds and their number. */
-int mi_isp_profile_enable(int max_launches);
-int mi_isp_profile_collect(float* avg_us, int* count);
+/* Events around the four data passes of every following mi_isp_pipeline12_reinhard[_batch] frame,
+ * recorded on the stream each pass runs on.  enable(n): time up to n frames (0 = off).
+ * collect(): waits for the recorded events; avg_us[k] = average duration of pass k in
+ * microseconds, *count = frames timed. */
+int mi_isp_profile_enable(int max_frames);
+int mi_isp_profile_collect(float avg_us[4], int* count);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // C ABI of the tile-based entry points (demosaic, fused load, fused config-2 pipeline) plus the
 // library-wide plumbing (version, error string, workspace size).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "isp_elementwise.h"
 #include "isp_tile.h"
@@ -102,20 +103,20 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
   return tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream);
 }
 
-// ---- measurement aid: HIP events around the dominant kernel, on the stream it runs on -----------------
+// ---- measurement aid: HIP events around each data pass, on the stream it runs on ---------------------
 #include <vector>
 static struct {
   bool on = false;
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> ev;     // 8 per frame: (start, stop) x 4 passes
   size_t used = 0;
 } g_prof;
 
-extern "C" int mi_isp_profile_enable(int max_launches) {
+extern "C" int mi_isp_profile_enable(int max_frames) {
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.clear();
   g_prof.used = 0;
-  g_prof.on = max_launches > 0;
-  for (int i = 0; i < 2 * max_launches; ++i) {
+  g_prof.on = max_frames > 0;
+  for (int i = 0; i < 8 * max_frames; ++i) {
     hipEvent_t e;
     MI_HIP(hipEventCreate(&e));
     g_prof.ev.push_back(e);
@@ -123,21 +124,34 @@ extern "C" int mi_isp_profile_enable(int max_launches) {
   return 0;
 }
 
-extern "C" int mi_isp_profile_collect(float* avg_us, int* count) {
+extern "C" int mi_isp_profile_collect(float avg_us[4], int* count) {
   MI_REQUIRE(avg_us && count, "profile_collect: null pointer");
-  double sum = 0;
+  double sum[4] = {0, 0, 0, 0};
   int n = 0;
-  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-    float ms = 0.f;
-    MI_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
-    MI_HIP(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
-    sum += ms * 1e3;
-    ++n;
+  for (size_t f = 0; f + 8 <= g_prof.used; f += 8, ++n) {
+    for (int k = 0; k < 4; ++k) {
+      float ms = 0.f;
+      MI_HIP(hipEventSynchronize(g_prof.ev[f + 2 * k + 1]));
+      MI_HIP(hipEventElapsedTime(&ms, g_prof.ev[f + 2 * k], g_prof.ev[f + 2 * k + 1]));
+      sum[k] += ms * 1e3;
+    }
   }
-  *avg_us = n ? (float)(sum / n) : 0.f;
+  for (int k = 0; k < 4; ++k) avg_us[k] = n ? (float)(sum[k] / n) : 0.f;
   *count = n;
   g_prof.used = 0;
   return 0;
+}
+
+// RAII-less helper: events of pass k of the frame whose slots start at `base` (or nothing)
+struct PassTimer {
+  size_t base; bool on; hipStream_t s;
+  int begin(int k) const { if (on) MI_HIP(hipEventRecord(g_prof.ev[base + 2 * k], s)); return 0; }
+  int end(int k) const { if (on) MI_HIP(hipEventRecord(g_prof.ev[base + 2 * k + 1], s)); return 0; }
+};
+static PassTimer pass_timer(hipStream_t s) {
+  PassTimer t = {g_prof.used, g_prof.on && g_prof.used + 8 <= g_prof.ev.size(), s};
+  if (t.on) g_prof.used += 8;
+  return t;
 }
 
 // One frame of the fused config-2 chain: four tile passes + three finalize launches.
@@ -151,20 +165,67 @@ static int pipeline_frame(tile::Params p, int pattern, int work_dtype, float int
   fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
   fa.n_px = (float)((int64_t)p.H * p.W); fa.intensity = intensity; fa.la = p.la; fa.ca = p.ca;
   fa.bounds_post = work_dtype == MI_F16 ? 2 : 1;
-  if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_MINMAX, s)) return rc;      // tonemap.py:146
-  if (int rc = ew::finalize(ew::FIN_BOUNDS, fa, s)) return rc;
-  if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STATS, s)) return rc;       // :147-149
-  if (int rc = ew::finalize(ew::FIN_STATS, fa, s)) return rc;
-  if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_RH_MINMAX, s)) return rc;   // :150,153
-  if (int rc = ew::finalize(ew::FIN_BOUNDS2, fa, s)) return rc;
-  const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-  if (timed) MI_HIP(hipEventRecord(g_prof.ev[g_prof.used], s));
-  const int rc = tile::launch(p, work_dtype, pattern, tile::EPI_RH_STORE, s);              // :154
-  if (timed) {
-    MI_HIP(hipEventRecord(g_prof.ev[g_prof.used + 1], s));
-    g_prof.used += 2;
+  const PassTimer tm = pass_timer(s);
+  static const int epis[4] = {tile::EPI_MINMAX, tile::EPI_STATS, tile::EPI_RH_MINMAX, tile::EPI_RH_STORE};
+  static const int fins[3] = {ew::FIN_BOUNDS, ew::FIN_STATS, ew::FIN_BOUNDS2};   // tonemap.py:146, :147-149, :150-153, :154
+  for (int k = 0; k < 4; ++k) {
+    if (int rc = tm.begin(k)) return rc;
+    if (int rc = tile::launch(p, work_dtype, pattern, epis[k], s)) return rc;
+    if (int rc = tm.end(k)) return rc;
+    if (k < 3)
+      if (int rc = ew::finalize(fins[k], fa, s)) return rc;
   }
-  return rc;
+  return 0;
+}
+
+// The "cached" variant of the same chain, used when the output has the work dtype (f16 -> f16,
+// f32 -> f32): the first pass writes the demosaiced work-dtype image INTO THE OUTPUT BUFFER while
+// reducing its bounds; the three tonemap passes then run elementwise on that image, the last one in
+// place.  One demosaic instead of four (the path is vector-issue-bound) at the price
+// of re-reading the 6 B/px image three times (it stays resident in the 256 MB Infinity Cache).
+// which: -1 = the whole chain; 0..3 = only that data pass (measurement aid).
+static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, float gamma, float intensity,
+                                 float* ws, int which, hipStream_t s) {
+  float* fp = ws;
+  float* partials = ws + FP_COUNT;
+  const int cap = mi_partial_cap(p.H, p.W);
+  p.fp = fp; p.partials = partials; p.part_stride = cap;
+  p.out_dtype = work_dtype; p.out_scale = 1.f;
+  const PassTimer tm = which < 0 ? pass_timer(s) : PassTimer{0, false, s};
+  if (int rc = tm.begin(0)) return rc;
+  if (which < 0 || which == 0)
+    if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STORE_MINMAX, s)) return rc;   // bayer.py + tonemap.py:146
+  if (int rc = tm.end(0)) return rc;
+  if (which < 0) {
+    ew::FinArgs fa = {};
+    fa.partials = partials; fa.stride = cap; fa.nblocks = tile::num_tiles(p.H, p.W); fa.fp = fp;
+    fa.bounds_post = work_dtype == MI_F16 ? 2 : 1;
+    if (int rc = ew::finalize(ew::FIN_BOUNDS, fa, s)) return rc;
+  }
+  if (which == 0) return 0;
+  if (which >= 0)
+    return ew::tonemap_reinhard_tail(p.dst, p.dst, p.H, p.W, work_dtype, work_dtype, gamma, intensity, p.la, p.ca, ws,
+                                     which, s);
+  for (int k = 1; k <= 3; ++k) {
+    if (int rc = tm.begin(k)) return rc;
+    if (int rc = ew::tonemap_reinhard_tail(p.dst, p.dst, p.H, p.W, work_dtype, work_dtype, gamma, intensity, p.la,
+                                           p.ca, ws, k, s))
+      return rc;
+    if (int rc = tm.end(k)) return rc;
+    if (k < 3) {
+      ew::FinArgs fa = {};
+      fa.partials = partials; fa.stride = cap; fa.fp = fp;
+      fa.nblocks = ew::tail_blocks(p.H, p.W);
+      fa.n_px = (float)((int64_t)p.H * p.W); fa.intensity = intensity; fa.la = p.la; fa.ca = p.ca;
+      if (int rc = ew::finalize(k == 1 ? ew::FIN_STATS : ew::FIN_BOUNDS2, fa, s)) return rc;
+    }
+  }
+  return 0;
+}
+
+static bool use_cached(const tile::Params& p, int work_dtype, int out_dtype) {
+  static const bool off = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
+  return !off && work_dtype == out_dtype && p.vec_store;
 }
 
 static int pipeline_params(tile::Params& p, int H, int W, int ids_format, int pattern, const float* ccm9,
@@ -192,6 +253,8 @@ extern "C" int mi_isp_pipeline12_reinhard(const uint8_t* packed, void* out, int 
   if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, "pipeline12_reinhard")) return rc;
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
+  if (use_cached(p, work_dtype, out_dtype))
+    return pipeline_frame_cached(p, pattern, work_dtype, gamma, intensity, static_cast<float*>(ws), -1, (hipStream_t)stream);
   return pipeline_frame(p, pattern, work_dtype, intensity, static_cast<float*>(ws), (hipStream_t)stream);
 }
 
@@ -214,9 +277,12 @@ extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, vo
     if (int rc = packed_params(p, packed[i], H, W, 12, ids_format, work_dtype, "pipeline12_reinhard_batch")) return rc;
     p.dst = out[i];
     p.vec_store = vec_store_ok(out[i], W, out_dtype);
-    if (int rc = pipeline_frame(p, pattern, work_dtype, intensity, static_cast<float*>(ws) + (size_t)i * ws_floats,
-                                (hipStream_t)streams[i % n_streams]))
-      return rc;
+    float* wsi = static_cast<float*>(ws) + (size_t)i * ws_floats;
+    hipStream_t si = (hipStream_t)streams[i % n_streams];
+    const int rc = use_cached(p, work_dtype, out_dtype)
+                       ? pipeline_frame_cached(p, pattern, work_dtype, gamma, intensity, wsi, -1, si)
+                       : pipeline_frame(p, pattern, work_dtype, intensity, wsi, si);
+    if (rc) return rc;
   }
   return 0;
 }
@@ -236,6 +302,8 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
   float* fp = static_cast<float*>(ws);
+  if (use_cached(p, work_dtype, out_dtype) && debug_skip == 0)
+    return pipeline_frame_cached(p, pattern, work_dtype, gamma, 1.0f, fp, pass, (hipStream_t)stream);
   p.fp = fp; p.partials = fp + FP_COUNT; p.part_stride = mi_partial_cap(H, W);
   p.debug_skip = debug_skip;
   static const int epi[4] = {tile::EPI_MINMAX, tile::EPI_STATS, tile::EPI_RH_MINMAX, tile::EPI_RH_STORE};

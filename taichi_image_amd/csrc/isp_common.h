@@ -114,6 +114,50 @@ MI_DEV void block_reduce_store(const float (&v)[NV], const int (&op)[NV], float 
   }
 }
 
+// ---- wave-cooperative 24-element-per-lane IO ----------------------------------------------------------
+// Interleaved RGB puts 8 pixels = 24 elements = 48 bytes (f16) in each lane.  Accessed directly that
+// is three 16-byte accesses per lane at a 48-byte lane stride, which the memory pipeline serves at
+// 3.7 TB/s (measured, scratch/store_bench.hip) against 6.2 TB/s for accesses that are contiguous
+// across the wave.  These helpers move a wave's 64 x 24 elements between global memory and
+// registers with wave-contiguous accesses, transposing through a per-wave LDS buffer
+// (no block barrier: LDS operations of one wave execute in order).
+template <class T> struct IoUnit { typedef uint4 type; };
+template <> struct IoUnit<uint8_t> { typedef uint2 type; };
+template <class T> struct IoUnits { static constexpr int value = (int)(sizeof(T) * 24 / sizeof(typename IoUnit<T>::type)); };
+constexpr int WAVE_IO_BYTES = 64 * 24 * 4;          // per-wave LDS staging, sized for 4-byte elements
+
+template <class T>
+MI_DEV void wave_load24(const T* gptr, int lane, void* lbuf_, T (&t)[24]) {
+  typedef typename IoUnit<T>::type U;
+  constexpr int N = IoUnits<T>::value;
+  U* lbuf = static_cast<U*>(lbuf_);
+  const U* g = reinterpret_cast<const U*>(gptr);
+#pragma unroll
+  for (int j = 0; j < N; ++j) lbuf[j * 64 + lane] = g[j * 64 + lane];
+  __builtin_amdgcn_wave_barrier();
+  U mine[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) mine[j] = lbuf[lane * N + j];
+  __builtin_memcpy(t, mine, sizeof(mine));
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class T>
+MI_DEV void wave_store24(T* gptr, int lane, void* lbuf_, const T (&t)[24]) {
+  typedef typename IoUnit<T>::type U;
+  constexpr int N = IoUnits<T>::value;
+  U* lbuf = static_cast<U*>(lbuf_);
+  U mine[N];
+  __builtin_memcpy(mine, t, sizeof(mine));
+#pragma unroll
+  for (int j = 0; j < N; ++j) lbuf[lane * N + j] = mine[j];
+  __builtin_amdgcn_wave_barrier();
+  U* g = reinterpret_cast<U*>(gptr);
+#pragma unroll
+  for (int j = 0; j < N; ++j) g[j * 64 + lane] = lbuf[j * 64 + lane];
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- per-frame workspace layout (floats) ---------------------------------------------------------
 // [0, 64)            : FrameParams -- scalars produced by the finalize kernels, read by later passes
 // [64, 64 + 8*cap)   : per-block partials, SoA: partial[k][block]

@@ -4,6 +4,8 @@
 #include "isp_elementwise.h"
 #include "isp_math.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace {
@@ -319,6 +321,8 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
   TO* dst = static_cast<TO*>(a.dst);
   const int64_t n_groups = (a.n_px + 7) / 8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr bool STORES = MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2;
 
   float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f, maxout_inv = 1.f;
   ReinhardK rk;
@@ -334,14 +338,25 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
   StatsAcc st; st.init();
 
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
+  __shared__ __attribute__((aligned(16))) unsigned char io_buf[EW_THREADS / 64][WAVE_IO_BYTES];
+  const int lane = threadIdx.x & 63;
+  void* wbuf = io_buf[threadIdx.x >> 6];
+
+  // One group = 8 pixels = 24 elements.  FULL: the wave's 64 groups are whole, aligned and
+  // contiguous, no orientation transform -> wave-contiguous IO through LDS and straight-line code
+  // without per-pixel tests.  CA0: color_adapt == 0 (one pow/px).
+  auto group = [&](auto full_c, auto ca0_c, int64_t g) {
+    constexpr bool FULL = decltype(full_c)::value;
+    constexpr bool CA0 = decltype(ca0_c)::value;
     const int64_t px0 = g * 8;
-    const int npx = (int)(a.n_px - px0 < 8 ? a.n_px - px0 : 8);
+    const int npx = FULL ? 8 : (int)(a.n_px - px0 < 8 ? a.n_px - px0 : 8);
     float v[24], o[24];
-    load24<TI>(src + px0 * 3, v, npx, a.vec_in);
+    // loads stay per-lane (3 x 16 B at a 48-B lane stride): measured as fast as wave-contiguous
+    // loads through LDS for reads; the stores below do go through LDS (3.7 -> 6.2 TB/s)
+    load24<TI>(src + px0 * 3, v, npx, FULL || a.vec_in);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool live = k < npx;
+      const bool live = FULL || k < npx;
       float x[3] = {v[3 * k], v[3 * k + 1], v[3 * k + 2]};
       if (MODE == PM_MINMAX) {
         if (live) {
@@ -356,8 +371,7 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
         float t[3], q[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) t[ch] = (x[ch] - lo) * inv;
-        if (rk.ca == 0.f) reinhard_px<true>(t, rk, q);
-        else reinhard_px<false>(t, rk, q);
+        reinhard_px<CA0>(t, rk, q);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = q[ch];
         if (live) vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
@@ -372,8 +386,7 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
           if (live) st.add(t[0], t[1], t[2]);
         } else {
           float q[3];
-          if (rk.ca == 0.f) reinhard_px<true>(t, rk, q);
-          else reinhard_px<false>(t, rk, q);
+          reinhard_px<CA0>(t, rk, q);
           if (MODE == PM_RH_MINMAX) {
             if (live) {
               vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
@@ -398,9 +411,21 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
     if (MODE == PM_LINEAR_STORE) linear_n<24>(o, lo, inv, a.gamma_inv, a.out_scale);
     if (MODE == PM_RH_STORE) linear_n<24>(o, lo2, inv2, a.gamma_inv, a.out_scale);
     if (MODE == PM_ISP_RH_P1) {
-      store24<TI>(static_cast<TI*>(a.inplace) + px0 * 3, o, npx, a.vec_in);
-    } else if (MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2) {
-      if (a.transform == MI_T_NONE) {
+      if constexpr (FULL) {
+        TI ot[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) ot[i] = cast_out<TI>(o[i]);
+        wave_store24<TI>(static_cast<TI*>(a.inplace) + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
+      } else {
+        store24<TI>(static_cast<TI*>(a.inplace) + px0 * 3, o, npx, a.vec_in);
+      }
+    } else if (STORES) {
+      if constexpr (FULL) {
+        TO ot[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) ot[i] = cast_out<TO>(o[i]);
+        wave_store24<TO>(dst + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
+      } else if (a.transform == MI_T_NONE) {
         store24<TO>(dst + px0 * 3, o, npx, a.vec_out);
       } else {
         // scatter: source pixel (r, c) -> the destination pixel that reads it (inverse of
@@ -429,6 +454,19 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
         }
       }
     }
+  };
+
+  // whole groups with aligned buffers and no transform take the FULL path; the rest (a ragged
+  // tail, unaligned views, transformed stores) the general one
+  // FULL needs all 64 groups of the wave whole: n_full is a multiple of 64 groups and `tid`
+  // strides by whole waves, so `g < n_full` is wave-uniform
+  const bool can_full = a.vec_in && (!STORES || (a.vec_out && a.transform == MI_T_NONE));
+  const int64_t n_full = can_full ? (a.n_px / 8) / 64 * 64 : 0;
+  if (rk.ca == 0.f) {
+    for (int64_t g = tid; g < n_full; g += stride) group(std::true_type{}, std::true_type{}, g);
+    for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::true_type{}, g);
+  } else {
+    for (int64_t g = tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, g);
   }
 
   if (MODE == PM_MINMAX || MODE == PM_RH_MINMAX || MODE == PM_ISP_RH_P1) {
@@ -616,6 +654,39 @@ static int launch_pass(int mode, int in_dtype, int out_dtype, const PassArgs& a,
   }
 }
 
+}  // namespace ew
+
+// forward: defined with the C ABI below
+static bool vec_ok(const void* p, int dtype);
+
+namespace ew {
+int tail_blocks(int H, int W) { return pass_blocks((int64_t)H * W, mi_partial_cap(H, W)); }
+int tonemap_reinhard_tail(const void* src, void* dst, int H, int W, int in_dtype, int out_dtype, float gamma,
+                          float intensity, float la, float ca, float* ws, int which, hipStream_t s) {
+  float* fp = ws;
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  PassArgs a = {};
+  a.src = src; a.dst = dst; a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
+  a.vec_in = vec_ok(src, in_dtype); a.vec_out = vec_ok(dst, out_dtype);
+  a.gamma_inv = 1.0f / gamma; a.la = la; a.ca = ca;
+  a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
+  const int nb = pass_blocks(a.n_px, cap);
+  FinArgs fa = {};
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
+  fa.n_px = (float)a.n_px; fa.intensity = intensity; fa.la = la; fa.ca = ca;
+  if (which < 0 || which == 1)
+    if (int rc = launch_pass(PM_STATS, in_dtype, out_dtype, a, nb, s)) return rc;       // tonemap.py:147-149
+  if (which < 0)
+    if (int rc = finalize(FIN_STATS, fa, s)) return rc;
+  if (which < 0 || which == 2)
+    if (int rc = launch_pass(PM_RH_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;   // :150,153
+  if (which < 0)
+    if (int rc = finalize(FIN_BOUNDS2, fa, s)) return rc;
+  if (which < 0 || which == 3)
+    if (int rc = launch_pass(PM_RH_STORE, in_dtype, out_dtype, a, nb, s)) return rc;    // :154
+  return 0;
+}
 }  // namespace ew
 
 // =================================================================================================
@@ -850,7 +921,7 @@ extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, i
 }
 
 // ---- ISP tonemaps ----------------------------------------------------------------------------
-static bool vec_ok(const void* p, int dtype) { return mi_aligned(p, dtype == MI_U8 ? 8 : 16); }
+static bool vec_ok(const void* p, int dtype) { return mi_aligned(p, dtype == MI_U8 ? 8 : 16); }  // 24-element groups
 
 extern "C" int mi_isp_reinhard(void* image, uint8_t* out, int H, int W, int dtype, const float* state9, float gamma,
                                float intensity, float light_adapt, float color_adapt, int transform, void* ws,
