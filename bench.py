@@ -97,6 +97,58 @@ def cpu_baseline(packed_frame: np.ndarray):
                       f"(oracle/isp_oracle.py), host has {ncores} cores"}
 
 
+def isp_workload(args, rank, world, device):
+    """Configs 3 / 5: the stateful Camera16 chain on `--frames` cameras per rank per step."""
+    import torch.distributed as dist
+    import taichi_image_amd as ti
+    from taichi_image_amd import synthetic
+    shared = args.workload == "isp-shared-stats"
+    group = dist.group.WORLD if (shared and world > 1) else None
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, resize_width=1920, device=device, process_group=group)
+    host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(min(4, args.frames))]
+    frames = [torch.from_numpy(host[i % len(host)]).to(device) for i in range(args.frames)]
+
+    def step():
+        return isp.tonemap_reinhard([isp.load_packed12(f) for f in frames], gamma=0.6)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        out_bytes = 1440 * 1920 * 3
+        print(json.dumps({
+            "metric": "megapixels/sec end-to-end ISP, 4096x3072 RGGB12; % HBM roofline",
+            "value": round(world * args.frames * args.steps * MP / elapsed, 1), "unit": "MP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("config 5" if shared else "config 3") + ": Camera16(RGGB, resize_width=1920, "
+                       "moving_alpha=0.1) load_packed12 x frames + tonemap_reinhard(gamma=0.6) -> u8 1920x1440"
+                       + (", metering all-reduced over ranks (RCCL)" if shared else ""),
+                       "frames_per_rank_per_step": args.frames},
+            "us_per_frame": round(elapsed / (args.frames * args.steps) * 1e6, 2),
+            "pipeline_frac_of_hbm_roofline": round((BYTES_IN + out_bytes) * world * args.frames * args.steps / elapsed
+                                                   / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +157,10 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per rank (frames in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config2", choices=["config2", "isp", "isp-shared-stats"],
+                    help="config2 (default, the BASELINE metric) | isp: Camera16(resize_width=1920) load_packed12 + "
+                         "tonemap_reinhard(gamma=0.6), config 3 | isp-shared-stats: the same with the rolling metering "
+                         "statistics all-reduced over the ranks (config 5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,6 +177,9 @@ def main():
 
     from taichi_image_amd import synthetic
     from taichi_image_amd.pipeline import BatchPipeline
+
+    if args.workload != "config2":
+        return isp_workload(args, rank, world, device)
 
     # distinct synthetic frames per rank (seeds 1234 + k); 4 distinct, cycled
     n_distinct = min(4, args.frames)
