@@ -129,6 +129,10 @@ int mi_isp_tonemap_reinhard(const void* src_dev, void* dst_dev, int H, int W, in
 int mi_isp_load_packed(const uint8_t* packed_dev, void* rgb_dev, int H, int W, int bits,
                        int ids_format, int pattern, const float* ccm9_host, int work_dtype,
                        int Hd, int Wd, float scale, void* stream);
+/* 1 if mi_isp_load_packed can fuse a resize by `scale` (its LDS tile holds the source region of a
+ * 64x16 destination tile for scale >= ~0.39, any upscale); otherwise demosaic at full size and
+ * call mi_isp_resize_bilinear. */
+int mi_isp_load_packed_scale_supported(float scale);
 /* The stateless chain of test/pipeline.py:26-32 (BASELINE config 2) fused:
  * decode12(scaled, work_dtype) -> bayer_to_rgb -> tonemap_reinhard(dtype=out_dtype), four
  * passes over the packed frame, the only HBM traffic being packed-in and RGB-out. */

@@ -193,12 +193,24 @@ def camera_isp(name: str, dtype=types.f32):
                 w, h = (image_data.shape[1] // 2, image_data.shape[0])             # camera_isp.py:343
             assert w % 2 == 0 and h % 2 == 0, "image must be even size"
             src = image_data.to(self.device).contiguous()
-            rgb = torch.empty((h, w, 3), dtype=torch_dtype, device=self.device)
-            _native.check(_native.lib().mi_isp_load_packed(
+            L = _native.lib()
+            # camera_isp.py:302-312: output size and scale of resize_image
+            if self.resize_width > 0:
+                scale = self.resize_width / w
+                out_size = (self.resize_width, round(h * scale))
+            elif self.scale is not None:
+                scale = self.scale
+                out_size = (round(w * scale), round(h * scale))
+            else:
+                scale, out_size = 0.0, (w, h)
+            fused = scale > 0 and min(out_size) > 0 and L.mi_isp_load_packed_scale_supported(float(scale))
+            wd, hd = out_size if fused else (w, h)
+            rgb = torch.empty((hd, wd, 3), dtype=torch_dtype, device=self.device)
+            _native.check(L.mi_isp_load_packed(
                 src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
-                _native.ccm_arg(self.color_correct_matrix), dtype.code, h, w, 0.0,
+                _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, float(scale) if fused else 0.0,
                 _native.stream_ptr(self.device)))
-            return self.resize_image(rgb)
+            return rgb if fused else self.resize_image(rgb)
 
         def load_packed12(self, image_data, ids_format=False):
             """camera_isp.py:333-340: unpack + demosaic (+ccm) fused in one pass over the packed frame."""

@@ -5,6 +5,7 @@
 
 #include "isp_elementwise.h"
 #include "isp_tile.h"
+#include "isp_resize_tile.h"
 
 static thread_local char g_err[512] = "";
 
@@ -96,12 +97,22 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
   tile::Params p = {};
   if (int rc = fill_common(p, H, W, pattern, ccm9, "load_packed")) return rc;
   if (int rc = packed_params(p, packed, H, W, bits, ids_format, work_dtype, "load_packed")) return rc;
-  MI_REQUIRE(scale <= 0.f, "load_packed: fused resize not available in this build; resize separately");
-  MI_REQUIRE(Hd == H && Wd == W, "load_packed: output shape must equal the frame when scale <= 0");
   p.dst = rgb; p.out_dtype = work_dtype; p.out_scale = 1.f;
+  if (scale > 0.f) {
+    // unpack -> demosaic -> bilinear fused (isp_resize_tile.h); the caller checks the scale first
+    MI_REQUIRE(rtile::scales_fit(scale, scale), "load_packed: scale %g is outside the fused kernel's range "
+               "(mi_isp_load_packed_scale_supported); resize separately", (double)scale);
+    MI_REQUIRE(Hd > 0 && Wd > 0 && H >= 2 && W >= 2, "load_packed: bad output shape %dx%d", Hd, Wd);
+    rtile::RParams rp = {};
+    rp.t = p; rp.Hd = Hd; rp.Wd = Wd; rp.s0 = scale; rp.s1 = scale;
+    return rtile::launch(rp, work_dtype, pattern, (hipStream_t)stream);
+  }
+  MI_REQUIRE(Hd == H && Wd == W, "load_packed: output shape must equal the frame when scale <= 0");
   p.vec_store = vec_store_ok(rgb, W, work_dtype);
   return tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream);
 }
+
+extern "C" int mi_isp_load_packed_scale_supported(float scale) { return rtile::scales_fit(scale, scale) ? 1 : 0; }
 
 // ---- measurement aid: HIP events around each data pass, on the stream it runs on ---------------------
 #include <vector>

@@ -345,6 +345,38 @@ def test_isp_load_packed12_bit_exact(ti, rng, dev, cam, work, kw):
     assert_exact(got.cpu().numpy(), ref, f"{cam}.load_packed12 {kw}")
 
 
+@pytest.mark.parametrize("p", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape,kw", [((98, 168), dict(scale=1.3)), ((98, 168), dict(scale=0.3)),      # upscale; unfused fallback
+                                      ((70, 170), dict(resize_width=90)), ((34, 136), dict(scale=0.46875)),
+                                      ((130, 264), dict(resize_width=124, correct_colors=True))])
+def test_isp_load_packed12_fused_resize(ti, rng, dev, p, shape, kw):
+    """unpack -> demosaic -> bilinear in one kernel (csrc/isp_resize_tile.h): every pattern, widths
+    that are not a multiple of 8 (byte-path fill), borders, colour matrix, up- and down-scaling."""
+    packed = natural_packed12(rng, *shape, pattern=p)
+    isp = ti.Camera16(pat(ti, p), device=dev, **kw)
+    got = isp.load_packed12(torch.from_numpy(packed).to(dev))
+    ccm = O.isp_color_matrix(kw.get("correct_colors", False), O.DEFAULT_WB, O.DEFAULT_CC)
+    ref = O.isp_load_packed12(packed, "f16", p, correct_colors=ccm, resize_width=kw.get("resize_width", 0),
+                              scale=kw.get("scale"))
+    assert_exact(got.cpu().numpy(), ref, f"fused resize {shape} p{p} {kw}")
+
+
+def test_isp_load_packed12_config3_full_size(ti, dev):
+    """BASELINE config 3: 4096x3072 packed-12 -> Camera16(resize_width=1920) -> f16 (1440, 1920, 3)."""
+    from oracle import c_oracle
+    from taichi_image_amd.synthetic import synthetic_packed12
+    packed = synthetic_packed12(1)
+    isp = ti.Camera16(ti.BayerPattern.RGGB, resize_width=1920, device=dev)
+    got = isp.load_packed12(torch.from_numpy(packed).to(dev)).cpu().numpy()
+    assert got.shape == (1440, 1920, 3) and got.dtype == np.float16
+    if c_oracle.available():      # full-size demosaic from the C oracle (fast), resize from the NumPy oracle
+        cfa = c_oracle.decode12_scaled(packed, work="f16").reshape(3072, 4096)
+        rgb = c_oracle.demosaic(cfa, 0, round_f16=True).astype(np.float16)
+    else:
+        rgb = O.bayer_to_rgb(O.decode12(packed, "f16", scaled=True))
+    assert_exact(got, O.resize_bilinear(rgb, (1920, 1440), 1920 / 4096), "config 3 load_packed12")
+
+
 def test_isp_other_loaders(ti, rng, dev):
     isp = ti.Camera16(ti.BayerPattern.GBRG, device=dev, resize_width=40)
     raw16 = rng.integers(0, 65536, (48, 64)).astype(np.uint16)
