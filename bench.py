@@ -226,7 +226,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("pass3_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("pass0_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {

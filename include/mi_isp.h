@@ -106,6 +106,16 @@ int mi_isp_metering_sums(const void* const* images_host, int n_images, int H, in
 int mi_isp_reinhard(void* image_dev, uint8_t* out_dev, int H, int W, int dtype,
                     const float* state9_dev, float gamma, float intensity, float light_adapt,
                     float color_adapt, int transform, void* ws_dev, void* stream);
+/* The per-image loop of ISP.tonemap_reinhard / tonemap_linear (camera_isp.py:399-403,409-413) in
+ * one call: n images of the same shape, 4 (Reinhard) or 2 (linear) launches in total instead of per
+ * image.  images_host / outs_host: host arrays of device pointers. */
+int mi_isp_reinhard_batch(void* const* images_host, uint8_t* const* outs_host, int n, int H, int W,
+                          int dtype, const float* state9_dev, float gamma, float intensity,
+                          float light_adapt, float color_adapt, int transform, void* ws_dev,
+                          void* stream);
+int mi_isp_linear_batch(const void* const* images_host, uint8_t* const* outs_host, int n, int H,
+                        int W, int dtype, const float* state9_dev, float gamma, int transform,
+                        void* ws_dev, void* stream);
 /* linear_kernel (camera_isp.py:220-227 -> tonemap.py:12-17). */
 int mi_isp_linear(const void* image_dev, uint8_t* out_dev, int H, int W, int dtype,
                   const float* state9_dev, float gamma, int transform, void* ws_dev, void* stream);

@@ -289,10 +289,14 @@ def camera_isp(name: str, dtype=types.f32):
             self.update_metering(images)
             outputs = [torch.empty(_out_shape(image, self.transform), dtype=torch.uint8, device=self.device)
                        for image in images]
-            for output, image in zip(outputs, images):
-                # the orientation transform (camera_isp.py:403) is folded into the u8 store
-                reinhard_kernel(image, output, self.metrics, gamma, intensity, light_adapt, color_adapt,
-                                self.transform)
+            # one batched call for the whole list (the reference loops, camera_isp.py:400-401); the
+            # orientation transform (:403) is folded into the u8 store
+            H, W = images[0].shape[:2]
+            ws = _native.workspace(H, W, self.device)
+            _native.check(_native.lib().mi_isp_reinhard_batch(
+                _native.ptr_array(images), _native.ptr_array(outputs), len(images), H, W, dtype.code,
+                self.metrics.data_ptr(), float(gamma), float(intensity), float(light_adapt), float(color_adapt),
+                interpolate.transform_code(self.transform), ws.data_ptr(), _native.stream_ptr(self.device)))
             return outputs
 
         def tonemap_linear(self, images: List[torch.Tensor], gamma: float = 1.0):
@@ -302,8 +306,12 @@ def camera_isp(name: str, dtype=types.f32):
             self.update_metering(images)
             outputs = [torch.empty(_out_shape(image, self.transform), dtype=torch.uint8, device=self.device)
                        for image in images]
-            for output, image in zip(outputs, images):
-                linear_kernel(image, output, self.metrics, gamma, self.transform)
+            H, W = images[0].shape[:2]
+            ws = _native.workspace(H, W, self.device)
+            _native.check(_native.lib().mi_isp_linear_batch(
+                _native.ptr_array(images), _native.ptr_array(outputs), len(images), H, W, dtype.code,
+                self.metrics.data_ptr(), float(gamma), interpolate.transform_code(self.transform), ws.data_ptr(),
+                _native.stream_ptr(self.device)))
             return outputs
 
     ISP.reinhard_kernel = staticmethod(reinhard_kernel)

@@ -311,14 +311,20 @@ struct PassArgs {
   int vec_in, vec_out;
   float gamma_inv, la, ca, out_scale;
   int transform, H, W;      // optional orientation transform fused into the store (u8 ISP outputs)
+  // batched launch (grid.y = image): per-image source / destination pointers and max_out scalars
+  int batched;
+  const float* maxouts;     // PM_ISP_RH_P2: max_out per image (camera_isp.py:190,213)
+  ew::PtrList srcs, dsts;
 };
 
 template <class TI, class TO, int MODE>
 __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) {
 #pragma clang fp contract(fast)
   __shared__ float red[4][8];
-  const TI* src = static_cast<const TI*>(a.src);
-  TO* dst = static_cast<TO*>(a.dst);
+  const TI* src = static_cast<const TI*>(a.batched ? a.srcs.p[blockIdx.y] : a.src);
+  TO* dst = static_cast<TO*>(a.batched ? const_cast<void*>(a.dsts.p[blockIdx.y]) : a.dst);
+  TI* inplace = a.batched ? const_cast<TI*>(src) : static_cast<TI*>(a.inplace);
+  const int pblock = a.batched ? blockIdx.y * gridDim.x + blockIdx.x : blockIdx.x;
   const int64_t n_groups = (a.n_px + 7) / 8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
     rk.mean3[0] = a.fp[FP_MEAN3]; rk.mean3[1] = a.fp[FP_MEAN3 + 1]; rk.mean3[2] = a.fp[FP_MEAN3 + 2];
   }
   if (MODE == PM_RH_STORE) { lo2 = a.fp[FP_LO2]; inv2 = a.fp[FP_INV2]; }
-  if (MODE == PM_ISP_RH_P2) maxout_inv = 1.0f / a.fp[FP_MAXOUT];
+  if (MODE == PM_ISP_RH_P2) maxout_inv = 1.0f / (a.batched ? a.maxouts[blockIdx.y] : a.fp[FP_MAXOUT]);
 
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
   StatsAcc st; st.init();
@@ -415,9 +421,9 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
         TI ot[24];
 #pragma unroll
         for (int i = 0; i < 24; ++i) ot[i] = cast_out<TI>(o[i]);
-        wave_store24<TI>(static_cast<TI*>(a.inplace) + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
+        wave_store24<TI>(inplace + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
       } else {
-        store24<TI>(static_cast<TI*>(a.inplace) + px0 * 3, o, npx, a.vec_in);
+        store24<TI>(inplace + px0 * 3, o, npx, a.vec_in);
       }
     } else if (STORES) {
       if constexpr (FULL) {
@@ -472,11 +478,11 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
   if (MODE == PM_MINMAX || MODE == PM_RH_MINMAX || MODE == PM_ISP_RH_P1) {
     const float v2[2] = {vmin, vmax};
     const int op[2] = {0, 1};
-    block_reduce_store<2>(v2, op, red, a.partials, a.part_stride, blockIdx.x);
+    block_reduce_store<2>(v2, op, red, a.partials, a.part_stride, pblock);
   } else if (MODE == PM_STATS) {
     const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[7] = {0, 1, 2, 2, 2, 2, 2};
-    block_reduce_store<7>(v7, op, red, a.partials, a.part_stride, blockIdx.x);
+    block_reduce_store<7>(v7, op, red, a.partials, a.part_stride, pblock);
   }
 }
 
@@ -571,6 +577,21 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(int mode, const e
   ew::finalize_scalars(mode, a, tot);
 }
 
+// max_out of every image of a batched ISP Reinhard pass 1: block i folds image i's partial maxima
+__global__ __launch_bounds__(EW_THREADS) void maxout_batch_kernel(const float* __restrict__ pmax, int nb,
+                                                                  float* __restrict__ maxouts) {
+  __shared__ float sh[EW_THREADS / 64];
+  float m = -__builtin_inff();
+  for (int i = threadIdx.x; i < nb; i += EW_THREADS) m = fmaxf(m, pmax[(size_t)blockIdx.x * nb + i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < EW_THREADS / 64; ++w) m = fmaxf(m, sh[w]);
+    maxouts[blockIdx.x] = fmaxf(1e-6f, m);                               // camera_isp.py:190,213
+  }
+}
+
 __global__ void isp_reinhard_prep_kernel(const float* state9, float* fp, float intensity, float ca) {
   // camera_isp.py:186-195
   const float bmin = state9[0], bmax = state9[1], lmin = state9[2], lmax = state9[3];
@@ -602,10 +623,10 @@ int isp_reinhard_prep(const float* state9, float* fp, float intensity, float ca,
 }
 
 template <class TI, class TO>
-static int launch_pass_t(int mode, const PassArgs& a, int nblocks, hipStream_t s) {
+static int launch_pass_t(int mode, const PassArgs& a, int nblocks, hipStream_t s, int ny = 1) {
 #define MI_PASS(M)                                                                              \
   case M:                                                                                       \
-    hipLaunchKernelGGL((rgb_pass_kernel<TI, TO, M>), dim3(nblocks), dim3(EW_THREADS), 0, s, a); \
+    hipLaunchKernelGGL((rgb_pass_kernel<TI, TO, M>), dim3(nblocks, ny), dim3(EW_THREADS), 0, s, a); \
     break;
   switch (mode) {
     MI_PASS(PM_MINMAX) MI_PASS(PM_STATS) MI_PASS(PM_RH_MINMAX) MI_PASS(PM_RH_STORE)
@@ -627,7 +648,7 @@ static int pass_blocks(int64_t n_px, int cap) {
   return (int)b;
 }
 
-static int launch_pass(int mode, int in_dtype, int out_dtype, const PassArgs& a, int nblocks, hipStream_t s) {
+static int launch_pass(int mode, int in_dtype, int out_dtype, const PassArgs& a, int nblocks, hipStream_t s, int ny = 1) {
   // instantiate the (in, out) pairs the API can produce: reductions ignore TO
   const bool reduce_only = mode == PM_MINMAX || mode == PM_STATS || mode == PM_RH_MINMAX || mode == PM_ISP_RH_P1;
   if (reduce_only) out_dtype = MI_U8;
@@ -635,20 +656,20 @@ static int launch_pass(int mode, int in_dtype, int out_dtype, const PassArgs& a,
 #define MI_IN(DT, TI)                                                                    \
   case DT:                                                                               \
     switch (out_dtype) {                                                                 \
-      case MI_U8: return launch_pass_t<TI, uint8_t>(mode, a, nblocks, s);                \
-      case MI_U16: return launch_pass_t<TI, uint16_t>(mode, a, nblocks, s);              \
-      case MI_F16: return launch_pass_t<TI, half_t>(mode, a, nblocks, s);                \
-      default: return launch_pass_t<TI, float>(mode, a, nblocks, s);                     \
+      case MI_U8: return launch_pass_t<TI, uint8_t>(mode, a, nblocks, s, ny);                \
+      case MI_U16: return launch_pass_t<TI, uint16_t>(mode, a, nblocks, s, ny);              \
+      case MI_F16: return launch_pass_t<TI, half_t>(mode, a, nblocks, s, ny);                \
+      default: return launch_pass_t<TI, float>(mode, a, nblocks, s, ny);                     \
     }
     MI_IN(MI_U8, uint8_t)
     MI_IN(MI_U16, uint16_t)
     MI_IN(MI_F16, half_t)
     default:
       switch (out_dtype) {
-        case MI_U8: return launch_pass_t<float, uint8_t>(mode, a, nblocks, s);
-        case MI_U16: return launch_pass_t<float, uint16_t>(mode, a, nblocks, s);
-        case MI_F16: return launch_pass_t<float, half_t>(mode, a, nblocks, s);
-        default: return launch_pass_t<float, float>(mode, a, nblocks, s);
+        case MI_U8: return launch_pass_t<float, uint8_t>(mode, a, nblocks, s, ny);
+        case MI_U16: return launch_pass_t<float, uint16_t>(mode, a, nblocks, s, ny);
+        case MI_F16: return launch_pass_t<float, half_t>(mode, a, nblocks, s, ny);
+        default: return launch_pass_t<float, float>(mode, a, nblocks, s, ny);
       }
 #undef MI_IN
   }
@@ -948,6 +969,79 @@ extern "C" int mi_isp_reinhard(void* image, uint8_t* out, int H, int W, int dtyp
   fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
   if (int rc = finalize(FIN_MAXOUT, fa, s)) return rc;
   return launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s);
+}
+
+// N images of one tonemap_reinhard call (camera_isp.py:399-403) with 4 launches in total instead of
+// 4 per image: prep, pass 1 over all images (grid.y = image), per-image max_out, pass 2 over all.
+extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
+                                     const float* state9, float gamma, float intensity, float light_adapt,
+                                     float color_adapt, int transform, void* ws, void* stream) {
+  MI_REQUIRE(images && outs && state9 && ws, "reinhard_batch: null pointer");
+  MI_REQUIRE(n >= 0, "reinhard_batch: negative image count");
+  MI_REQUIRE(H > 0 && W > 0, "reinhard_batch: bad shape");
+  MI_REQUIRE(dtype == MI_F16 || dtype == MI_F32, "reinhard_batch: image must be f16 or f32");
+  MI_REQUIRE(gamma > 0.f, "reinhard_batch: gamma must be positive");
+  MI_REQUIRE(transform >= MI_T_NONE && transform <= MI_T_TRANSVERSE, "reinhard_batch: bad transform");
+  MI_REQUIRE(transform != MI_T_TRANSVERSE || H == W, "reinhard_batch: transverse needs a square image");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  if (n == 0) return 0;
+  if (int rc = isp_reinhard_prep(state9, fp, intensity, color_adapt, s)) return rc;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int m = n - i0 < 64 ? n - i0 : 64;
+    PassArgs a = {};
+    a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
+    a.vec_in = 1; a.vec_out = 1;
+    for (int i = 0; i < m; ++i) {
+      MI_REQUIRE(images[i0 + i] && outs[i0 + i], "reinhard_batch: image %d is null", i0 + i);
+      a.srcs.p[i] = images[i0 + i]; a.dsts.p[i] = outs[i0 + i];
+      a.vec_in = a.vec_in && vec_ok(images[i0 + i], dtype);
+      a.vec_out = a.vec_out && vec_ok(outs[i0 + i], MI_U8);
+    }
+    a.batched = 1;
+    a.gamma_inv = (float)(1.0 / (double)gamma); a.la = light_adapt; a.ca = color_adapt; a.out_scale = 255.f;
+    a.transform = transform; a.H = H; a.W = W;
+    int nb = pass_blocks(a.n_px, cap / m > 0 ? cap / m : 1);
+    float* maxouts = partials + (size_t)2 * cap;           // partial row 2: unused by the 2-row reductions
+    a.maxouts = maxouts;
+    if (int rc = launch_pass(PM_ISP_RH_P1, dtype, MI_U8, a, nb, s, m)) return rc;
+    hipLaunchKernelGGL(maxout_batch_kernel, dim3(m), dim3(EW_THREADS), 0, s, partials + cap, nb, maxouts);
+    MI_LAUNCH_CHECK();
+    if (int rc = launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s, m)) return rc;
+  }
+  return 0;
+}
+
+extern "C" int mi_isp_linear_batch(const void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
+                                   const float* state9, float gamma, int transform, void* ws, void* stream) {
+  MI_REQUIRE(images && outs && state9 && ws, "linear_batch: null pointer");
+  MI_REQUIRE(n >= 0 && H > 0 && W > 0, "linear_batch: bad shape");
+  MI_REQUIRE(dtype == MI_F16 || dtype == MI_F32, "linear_batch: image must be f16 or f32");
+  MI_REQUIRE(gamma > 0.f, "linear_batch: gamma must be positive");
+  MI_REQUIRE(transform >= MI_T_NONE && transform <= MI_T_TRANSVERSE, "linear_batch: bad transform");
+  MI_REQUIRE(transform != MI_T_TRANSVERSE || H == W, "linear_batch: transverse needs a square image");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  if (n == 0) return 0;
+  if (int rc = isp_reinhard_prep(state9, fp, 0.f, 0.f, s)) return rc;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int m = n - i0 < 64 ? n - i0 : 64;
+    PassArgs a = {};
+    a.fp = fp; a.n_px = (int64_t)H * W; a.vec_in = 1; a.vec_out = 1;
+    for (int i = 0; i < m; ++i) {
+      MI_REQUIRE(images[i0 + i] && outs[i0 + i], "linear_batch: image %d is null", i0 + i);
+      a.srcs.p[i] = images[i0 + i]; a.dsts.p[i] = outs[i0 + i];
+      a.vec_in = a.vec_in && vec_ok(images[i0 + i], dtype);
+      a.vec_out = a.vec_out && vec_ok(outs[i0 + i], MI_U8);
+    }
+    a.batched = 1;
+    a.gamma_inv = (float)(1.0 / (double)gamma); a.out_scale = 255.f;
+    a.transform = transform; a.H = H; a.W = W;
+    if (int rc = launch_pass(PM_LINEAR_STORE, dtype, MI_U8, a, pass_blocks(a.n_px, 1 << 30), s, m)) return rc;
+  }
+  return 0;
 }
 
 extern "C" int mi_isp_linear(const void* image, uint8_t* out, int H, int W, int dtype, const float* state9,
