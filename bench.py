@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per rank (frames in flight)")
+    ap.add_argument("--profile-every", type=int, default=5,
+                    help="HIP events around the passes of every n-th frame of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2", "isp", "isp-shared-stats"],
                     help="config2 (default, the BASELINE metric) | isp: Camera16(resize_width=1920) load_packed12 + "
@@ -199,7 +201,7 @@ def main():
         bp(frames)
     barrier()
     # events around every launch of the dominant kernel inside the timed region (rank 0's line)
-    _native.check(_native.lib().mi_isp_profile_enable(args.frames * args.steps))
+    _native.check(_native.lib().mi_isp_profile_enable(args.frames * args.steps, args.profile_every))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bp(frames)
@@ -207,7 +209,7 @@ def main():
     elapsed = time.perf_counter() - t0
     live_us, live_n = (ctypes.c_float * 4)(), ctypes.c_int(0)
     _native.check(_native.lib().mi_isp_profile_collect(live_us, ctypes.byref(live_n)))
-    _native.check(_native.lib().mi_isp_profile_enable(0))
+    _native.check(_native.lib().mi_isp_profile_enable(0, 1))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -170,11 +170,12 @@ int mi_isp_pipeline12_pass(const uint8_t* packed_dev, void* out_dev, int H, int 
                            float gamma, float light_adapt, float color_adapt, int pass,
                            void* ws_dev, void* stream);
 
-/* Events around the four data passes of every following mi_isp_pipeline12_reinhard[_batch] frame,
- * recorded on the stream each pass runs on.  enable(n): time up to n frames (0 = off).
- * collect(): waits for the recorded events; avg_us[k] = average duration of pass k in
- * microseconds, *count = frames timed. */
-int mi_isp_profile_enable(int max_frames);
+/* Events around the four data passes of following mi_isp_pipeline12_reinhard[_batch] frames,
+ * recorded on the stream each pass runs on.  enable(n, every): time every `every`-th frame, up to n
+ * frames (n = 0: off); an event between two launches costs a gap on the stream, so sampling keeps
+ * the measured run representative.  collect(): waits for the recorded events; avg_us[k] = average
+ * duration of pass k in microseconds, *count = frames timed. */
+int mi_isp_profile_enable(int max_frames, int every);
 int mi_isp_profile_collect(float avg_us[4], int* count);
 
 #ifdef __cplusplus

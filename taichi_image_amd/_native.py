@@ -53,7 +53,7 @@ SIGNATURES = {
                                                  _P, POINTER(_P), c_int]),
     "mi_isp_pipeline12_pass": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_float,
                                        c_float, c_float, c_int, _P, _P]),
-    "mi_isp_profile_enable": (c_int, [c_int]),
+    "mi_isp_profile_enable": (c_int, [c_int, c_int]),
     "mi_isp_profile_collect": (c_int, [POINTER(c_float), POINTER(c_int)]),   # float[4]
 }
 

@@ -118,15 +118,19 @@ extern "C" int mi_isp_load_packed_scale_supported(float scale) { return rtile::s
 #include <vector>
 static struct {
   bool on = false;
-  std::vector<hipEvent_t> ev;     // 8 per frame: (start, stop) x 4 passes
+  std::vector<hipEvent_t> ev;     // 8 per sampled frame: (start, stop) x 4 passes
   size_t used = 0;
+  int every = 1;                  // every n-th frame is sampled (events between launches cost gaps)
+  long frames_seen = 0;
 } g_prof;
 
-extern "C" int mi_isp_profile_enable(int max_frames) {
+extern "C" int mi_isp_profile_enable(int max_frames, int every) {
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.clear();
   g_prof.used = 0;
   g_prof.on = max_frames > 0;
+  g_prof.every = every > 0 ? every : 1;
+  g_prof.frames_seen = 0;
   for (int i = 0; i < 8 * max_frames; ++i) {
     hipEvent_t e;
     MI_HIP(hipEventCreate(&e));
@@ -160,7 +164,8 @@ struct PassTimer {
   int end(int k) const { if (on) MI_HIP(hipEventRecord(g_prof.ev[base + 2 * k + 1], s)); return 0; }
 };
 static PassTimer pass_timer(hipStream_t s) {
-  PassTimer t = {g_prof.used, g_prof.on && g_prof.used + 8 <= g_prof.ev.size(), s};
+  const bool sampled = g_prof.on && (g_prof.frames_seen++ % g_prof.every) == 0;
+  PassTimer t = {g_prof.used, sampled && g_prof.used + 8 <= g_prof.ev.size(), s};
   if (t.on) g_prof.used += 8;
   return t;
 }
@@ -207,29 +212,17 @@ static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, fl
   if (which < 0 || which == 0)
     if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STORE_MINMAX, s)) return rc;   // bayer.py + tonemap.py:146
   if (int rc = tm.end(0)) return rc;
-  if (which < 0) {
-    ew::FinArgs fa = {};
-    fa.partials = partials; fa.stride = cap; fa.nblocks = tile::num_tiles(p.H, p.W); fa.fp = fp;
-    fa.bounds_post = work_dtype == MI_F16 ? 2 : 1;
-    if (int rc = ew::finalize(ew::FIN_BOUNDS, fa, s)) return rc;
-  }
   if (which == 0) return 0;
-  if (which >= 0)
+  const ew::PullSrc bounds = {partials, cap, tile::num_tiles(p.H, p.W), work_dtype == MI_F16 ? 2 : 1};
+  if (which > 0)
     return ew::tonemap_reinhard_tail(p.dst, p.dst, p.H, p.W, work_dtype, work_dtype, gamma, intensity, p.la, p.ca, ws,
-                                     which, s);
+                                     which, bounds, s);
   for (int k = 1; k <= 3; ++k) {
     if (int rc = tm.begin(k)) return rc;
     if (int rc = ew::tonemap_reinhard_tail(p.dst, p.dst, p.H, p.W, work_dtype, work_dtype, gamma, intensity, p.la,
-                                           p.ca, ws, k, s))
+                                           p.ca, ws, k, bounds, s))
       return rc;
     if (int rc = tm.end(k)) return rc;
-    if (k < 3) {
-      ew::FinArgs fa = {};
-      fa.partials = partials; fa.stride = cap; fa.fp = fp;
-      fa.nblocks = ew::tail_blocks(p.H, p.W);
-      fa.n_px = (float)((int64_t)p.H * p.W); fa.intensity = intensity; fa.la = p.la; fa.ca = p.ca;
-      if (int rc = ew::finalize(k == 1 ? ew::FIN_STATS : ew::FIN_BOUNDS2, fa, s)) return rc;
-    }
   }
   return 0;
 }
@@ -316,9 +309,10 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
   if (use_cached(p, work_dtype, out_dtype) && debug_skip == 0)
     return pipeline_frame_cached(p, pattern, work_dtype, gamma, 1.0f, fp, pass, (hipStream_t)stream);
   p.fp = fp; p.partials = fp + FP_COUNT; p.part_stride = mi_partial_cap(H, W);
-  p.debug_skip = debug_skip;
+  p.debug_skip = debug_skip & 63;
   static const int epi[4] = {tile::EPI_MINMAX, tile::EPI_STATS, tile::EPI_RH_MINMAX, tile::EPI_RH_STORE};
-  return tile::launch(p, work_dtype, pattern, epi[pass], (hipStream_t)stream);
+  const int e = (debug_skip & 64) ? tile::EPI_STORE_MINMAX : epi[pass];   // bit 64: the cached pipeline's pass 0
+  return tile::launch(p, work_dtype, pattern, e, (hipStream_t)stream);
 }
 
 namespace tile { int occupancy_rggb(int epi); }

@@ -87,6 +87,15 @@ MI_DEV float op_add(float a, float b) { return a + b; }
 MI_DEV float wave_min(float v) { MI_ROW_REDUCE(fminf) return v; }
 MI_DEV float wave_max(float v) { MI_ROW_REDUCE(fmaxf) return v; }
 MI_DEV float wave_sum(float v) { MI_ROW_REDUCE(op_add) return v; }
+// fp64 variant for the sums of the pulled finalize (rgb_pass_kernel prologue)
+template <int CTRL> MI_DEV double dpp_mov(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+MI_DEV double op_add(double a, double b) { return a + b; }
+MI_DEV double wave_sum(double v) { MI_ROW_REDUCE(op_add) return v; }
 #undef MI_ROW_REDUCE
 
 // Block reduction of up to 8 values per thread for 256-thread blocks (4 waves): each wave

@@ -11,6 +11,10 @@
 namespace {
 
 constexpr int EW_THREADS = 256;
+// RGB passes: few fat blocks (2 per CU), so that the per-block prologue that folds the previous
+// pass's partials (pull_finalize) reads little in total and leaves few partials itself
+constexpr int PASS_THREADS = 512;
+constexpr int PASS_MAX_BLOCKS = 512;
 
 static inline int grid_for(int64_t work_items, int cap = 256 * 16) {
   int64_t b = (work_items + EW_THREADS - 1) / EW_THREADS;
@@ -244,6 +248,21 @@ __global__ __launch_bounds__(EW_THREADS) void transform_kernel(const T* __restri
 // ---------------------------------------------------------------------------------------------
 // 8-pixel (24-element) vector IO on (H, W, 3) images
 // ---------------------------------------------------------------------------------------------
+// the 24 elements of an aligned whole group, as loaded (issued early, converted when used)
+template <class T> MI_DEV void load24_raw(const T* p, T (&t)[24]) {
+  if (sizeof(T) == 1) {
+    const uint2* s = reinterpret_cast<const uint2*>(p);
+    uint2* d = reinterpret_cast<uint2*>(t);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+  } else {
+    constexpr int N = (int)(sizeof(T) * 24 / 16);
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint4* d = reinterpret_cast<uint4*>(t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = s[i];
+  }
+}
+
 template <class T> MI_DEV void load24(const T* p, float (&v)[24], int npx, bool vec) {
   if (vec && npx == 8) {
     T t[24];
@@ -315,12 +334,86 @@ struct PassArgs {
   int batched;
   const float* maxouts;     // PM_ISP_RH_P2: max_out per image (camera_isp.py:190,213)
   ew::PtrList srcs, dsts;
+  // Pulled finalize: instead of a one-block finalize launch between two passes, every block of the
+  // consuming pass folds the producer's per-block partials itself in its prologue (identical
+  // arithmetic in every block, so every block derives the same scalars); block 0 also publishes
+  // them to `fp_w` for the passes after this one.  pull_mode < 0: scalars come from `fp`.
+  int pull_mode = -1;       // ew::FinMode or -1
+  const float* pull_partials; int pull_stride, pull_n, pull_bounds_post;
+  float pull_npx, pull_intensity;
+  float* fp_w;
 };
 
+// Prologue of a pass with a pulled finalize: sh_fp = the FrameParams this block works with.
+template <int FIN>
+MI_DEV void pull_finalize(const PassArgs& a, float* sh_fp, double (*sh_tot)[PASS_THREADS / 64]) {
+  constexpr int mode = FIN;
+  constexpr int nrows = mode == ew::FIN_STATS ? 7 : 2;
+  // every load of the prologue is issued before the first use: one memory latency, which the
+  // caller's prefetch of its first image group shares
+  const float fp_mine = threadIdx.x < FP_COUNT ? a.fp[threadIdx.x] : 0.f;
+  constexpr int U = nrows == 2 ? 8 : 2;              // entries per thread and round (<= 16 loads)
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int base = 0; base < a.pull_n; base += U * PASS_THREADS) {
+    float v[U][nrows];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * PASS_THREADS + threadIdx.x;
+      const bool ok = i < a.pull_n;
+#pragma unroll
+      for (int k = 0; k < nrows; ++k)
+        v[u][k] = ok ? a.pull_partials[(size_t)k * a.pull_stride + i] : (k == 0 ? __builtin_inff() : k == 1 ? -__builtin_inff() : 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mn = fminf(mn, v[u][0]); mx = fmaxf(mx, v[u][1]);
+#pragma unroll
+      for (int k = 2; k < nrows; ++k) sum[k - 2] += (double)v[u][k];
+    }
+  }
+  if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = fp_mine;
+  mn = wave_min(mn); mx = wave_max(mx);
+  if (nrows == 7) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sum[k] = wave_sum(sum[k]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh_tot[0][wave] = (double)mn; sh_tot[1][wave] = (double)mx;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sh_tot[k + 2][wave] = sum[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot[7];
+    tot[0] = sh_tot[0][0]; tot[1] = sh_tot[1][0];
+#pragma unroll
+    for (int k = 2; k < 7; ++k) tot[k] = sh_tot[k][0];
+    for (int w = 1; w < PASS_THREADS / 64; ++w) {
+      tot[0] = fmin(tot[0], sh_tot[0][w]); tot[1] = fmax(tot[1], sh_tot[1][w]);
+#pragma unroll
+      for (int k = 2; k < 7; ++k) tot[k] += sh_tot[k][w];
+    }
+    ew::FinArgs fa = {};
+    fa.fp = sh_fp; fa.n_px = a.pull_npx; fa.intensity = a.pull_intensity; fa.la = a.la; fa.ca = a.ca;
+    fa.bounds_post = a.pull_bounds_post;
+    if (!(a.pull_mode & 0x100)) {
+      ew::finalize_scalars(mode, fa, tot);
+    }
+  }
+  __syncthreads();
+}
+
+// per-wave LDS staging of the wave-cooperative stores decides whether two 1024-thread blocks fit a CU
+template <class TI, class TO, int MODE> constexpr int pass_lds_bytes() {
+  const bool uses_io = MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2 || MODE == PM_ISP_RH_P1;
+  return uses_io ? (PASS_THREADS / 64) * 64 * 24 * (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO)) : 0;
+}
 template <class TI, class TO, int MODE>
-__global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) {
+__global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArgs a) {
 #pragma clang fp contract(fast)
-  __shared__ float red[4][8];
+  __shared__ float red[PASS_THREADS / 64][8];
   const TI* src = static_cast<const TI*>(a.batched ? a.srcs.p[blockIdx.y] : a.src);
   TO* dst = static_cast<TO*>(a.batched ? const_cast<void*>(a.dsts.p[blockIdx.y]) : a.dst);
   TI* inplace = a.batched ? const_cast<TI*>(src) : static_cast<TI*>(a.inplace);
@@ -330,23 +423,49 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   constexpr bool STORES = MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2;
 
+  // the pass's scalars: from the pulled finalize of the producer's partials, or from FrameParams
+  __shared__ float sh_fp[FP_COUNT];
+  __shared__ double sh_tot[7][PASS_THREADS / 64];
+  // which finalize a pass pulls is fixed by what it consumes
+  constexpr int PULL_FIN = MODE == PM_STATS || MODE == PM_LINEAR_STORE ? (int)ew::FIN_BOUNDS
+                           : MODE == PM_RH_MINMAX ? (int)ew::FIN_STATS
+                           : MODE == PM_RH_STORE ? (int)ew::FIN_BOUNDS2 : -1;
+  const bool pulled = PULL_FIN >= 0 && a.pull_mode >= 0;
+  const int lane = threadIdx.x & 63;
+
+  // Whole groups with aligned buffers and no transform take the FULL path (straight-line code, wave-
+  // cooperative stores); the rest (a ragged tail, unaligned views, transformed stores) the general one.
+  // FULL needs all 64 groups of the wave whole: n_full is a multiple of 64 groups and `tid` strides by
+  // whole waves, so `g < n_full` is wave-uniform.
+  const bool can_full = a.vec_in && (!STORES || (a.vec_out && a.transform == MI_T_NONE));
+  const int64_t n_full = can_full ? (a.n_px / 8) / 64 * 64 : 0;
+  // the first group's loads are in flight while the prologue folds the producer's partials
+  TI raw[24];
+  if (tid < n_full) load24_raw<TI>(src + tid * 24, raw);
+
+  if constexpr (PULL_FIN >= 0) {
+    if (pulled) pull_finalize<PULL_FIN>(a, sh_fp, sh_tot);
+  }
+  auto fpv = [&](int i) { return pulled ? sh_fp[i] : a.fp[i]; };
+
   float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f, maxout_inv = 1.f;
   ReinhardK rk;
   rk.la = a.la; rk.ca = a.ca; rk.map_key = 1.f; rk.ei = 1.f; rk.mean3[0] = rk.mean3[1] = rk.mean3[2] = 0.f;
-  if (MODE != PM_MINMAX && MODE != PM_ISP_RH_P2) { lo = a.fp[FP_LO]; inv = a.fp[FP_INV]; }
+  if (MODE != PM_MINMAX && MODE != PM_ISP_RH_P2) { lo = fpv(FP_LO); inv = fpv(FP_INV); }
   if (MODE == PM_RH_MINMAX || MODE == PM_RH_STORE || MODE == PM_ISP_RH_P1) {
-    rk.map_key = a.fp[FP_MAPKEY]; rk.ei = a.fp[FP_EI];
-    rk.mean3[0] = a.fp[FP_MEAN3]; rk.mean3[1] = a.fp[FP_MEAN3 + 1]; rk.mean3[2] = a.fp[FP_MEAN3 + 2];
+    rk.map_key = fpv(FP_MAPKEY); rk.ei = fpv(FP_EI);
+    rk.mean3[0] = fpv(FP_MEAN3); rk.mean3[1] = fpv(FP_MEAN3 + 1); rk.mean3[2] = fpv(FP_MEAN3 + 2);
   }
-  if (MODE == PM_RH_STORE) { lo2 = a.fp[FP_LO2]; inv2 = a.fp[FP_INV2]; }
+  if (MODE == PM_RH_STORE) { lo2 = fpv(FP_LO2); inv2 = fpv(FP_INV2); }
   if (MODE == PM_ISP_RH_P2) maxout_inv = 1.0f / (a.batched ? a.maxouts[blockIdx.y] : a.fp[FP_MAXOUT]);
 
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
   StatsAcc st; st.init();
 
-  __shared__ __attribute__((aligned(16))) unsigned char io_buf[EW_THREADS / 64][WAVE_IO_BYTES];
-  const int lane = threadIdx.x & 63;
-  void* wbuf = io_buf[threadIdx.x >> 6];
+  constexpr bool USES_IO = STORES || MODE == PM_ISP_RH_P1;
+  constexpr int IO_BYTES = 64 * 24 * (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));   // per-wave staging
+  __shared__ __attribute__((aligned(16))) unsigned char io_buf[USES_IO ? PASS_THREADS / 64 : 1][IO_BYTES];
+  void* wbuf = io_buf[USES_IO ? threadIdx.x >> 6 : 0];
 
   // One group = 8 pixels = 24 elements.  FULL: the wave's 64 groups are whole, aligned and
   // contiguous, no orientation transform -> wave-contiguous IO through LDS and straight-line code
@@ -359,7 +478,14 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
     float v[24], o[24];
     // loads stay per-lane (3 x 16 B at a 48-B lane stride): measured as fast as wave-contiguous
     // loads through LDS for reads; the stores below do go through LDS (3.7 -> 6.2 TB/s)
-    load24<TI>(src + px0 * 3, v, npx, FULL || a.vec_in);
+    if constexpr (FULL) {
+      // software pipeline: this group was loaded one iteration ago; start the next one now
+#pragma unroll
+      for (int i = 0; i < 24; ++i) v[i] = (float)raw[i];
+      if (g + stride < n_full) load24_raw<TI>(src + (g + stride) * 24, raw);
+    } else {
+      load24<TI>(src + px0 * 3, v, npx, a.vec_in);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const bool live = FULL || k < npx;
@@ -462,12 +588,6 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
     }
   };
 
-  // whole groups with aligned buffers and no transform take the FULL path; the rest (a ragged
-  // tail, unaligned views, transformed stores) the general one
-  // FULL needs all 64 groups of the wave whole: n_full is a multiple of 64 groups and `tid`
-  // strides by whole waves, so `g < n_full` is wave-uniform
-  const bool can_full = a.vec_in && (!STORES || (a.vec_out && a.transform == MI_T_NONE));
-  const int64_t n_full = can_full ? (a.n_px / 8) / 64 * 64 : 0;
   if (rk.ca == 0.f) {
     for (int64_t g = tid; g < n_full; g += stride) group(std::true_type{}, std::true_type{}, g);
     for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::true_type{}, g);
@@ -475,6 +595,12 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_pass_kernel(const PassArgs a) 
     for (int64_t g = tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, g);
   }
 
+  if constexpr (PULL_FIN >= 0) {
+    // block 0 publishes the pulled scalars for the passes after this one (off the critical path)
+    if (pulled && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < FP_COUNT && a.fp_w &&
+        ew::finalize_writes(PULL_FIN, threadIdx.x))
+      a.fp_w[threadIdx.x] = sh_fp[threadIdx.x];
+  }
   if (MODE == PM_MINMAX || MODE == PM_RH_MINMAX || MODE == PM_ISP_RH_P1) {
     const float v2[2] = {vmin, vmax};
     const int op[2] = {0, 1};
@@ -626,7 +752,7 @@ template <class TI, class TO>
 static int launch_pass_t(int mode, const PassArgs& a, int nblocks, hipStream_t s, int ny = 1) {
 #define MI_PASS(M)                                                                              \
   case M:                                                                                       \
-    hipLaunchKernelGGL((rgb_pass_kernel<TI, TO, M>), dim3(nblocks, ny), dim3(EW_THREADS), 0, s, a); \
+    hipLaunchKernelGGL((rgb_pass_kernel<TI, TO, M>), dim3(nblocks, ny), dim3(PASS_THREADS), 0, s, a); \
     break;
   switch (mode) {
     MI_PASS(PM_MINMAX) MI_PASS(PM_STATS) MI_PASS(PM_RH_MINMAX) MI_PASS(PM_RH_STORE)
@@ -641,9 +767,9 @@ static int launch_pass_t(int mode, const PassArgs& a, int nblocks, hipStream_t s
 // number of blocks an RGB pass over n_px pixels uses (== number of partials it leaves)
 static int pass_blocks(int64_t n_px, int cap) {
   int64_t groups = (n_px + 7) / 8;
-  int64_t b = (groups + EW_THREADS - 1) / EW_THREADS;
+  int64_t b = (groups + PASS_THREADS - 1) / PASS_THREADS;
   if (b < 1) b = 1;
-  if (b > 2048) b = 2048;
+  if (b > PASS_MAX_BLOCKS) b = PASS_MAX_BLOCKS;
   if (b > cap) b = cap;
   return (int)b;
 }
@@ -682,30 +808,51 @@ static bool vec_ok(const void* p, int dtype);
 
 namespace ew {
 int tail_blocks(int H, int W) { return pass_blocks((int64_t)H * W, mi_partial_cap(H, W)); }
+// The three data passes after the bounds pass of tonemap.py:146-154, chained by pulled finalizes
+// (PassArgs::pull_mode): pass 1 folds the bounds partials `bounds` of whoever produced the image,
+// pass 2 the statistics partials of pass 1, pass 3 the bounds partials of pass 2.  Workspace rows:
+// [0, 2 cap) the caller's bounds partials, [2 cap, 6 cap) pass 1's 7 rows, [6 cap, 7 cap) pass 2's 2 rows
+// (row stride TAIL_STRIDE).  which: -1 = all three, 1..3 = only that pass (measurement aid; the
+// partials of an earlier full run must still be in the workspace).
 int tonemap_reinhard_tail(const void* src, void* dst, int H, int W, int in_dtype, int out_dtype, float gamma,
-                          float intensity, float la, float ca, float* ws, int which, hipStream_t s) {
+                          float intensity, float la, float ca, float* ws, int which, const PullSrc& bounds,
+                          hipStream_t s) {
+  constexpr int TAIL_STRIDE = PASS_MAX_BLOCKS;    // the block limit of pass_blocks
   float* fp = ws;
   float* partials = fp + FP_COUNT;
-  const int cap = mi_partial_cap(H, W);
+  const int cap = mi_partial_cap(H, W);           // >= 4096: 7 rows fit in 4 cap, 2 rows in cap
+  float* stats_part = partials + 2 * (size_t)cap;
+  float* bounds2_part = partials + 6 * (size_t)cap;
   PassArgs a = {};
-  a.src = src; a.dst = dst; a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
+  a.src = src; a.dst = dst; a.fp = fp; a.fp_w = fp; a.n_px = (int64_t)H * W;
   a.vec_in = vec_ok(src, in_dtype); a.vec_out = vec_ok(dst, out_dtype);
   a.gamma_inv = 1.0f / gamma; a.la = la; a.ca = ca;
   a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
+  a.pull_npx = (float)a.n_px; a.pull_intensity = intensity;
   const int nb = pass_blocks(a.n_px, cap);
-  FinArgs fa = {};
-  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
-  fa.n_px = (float)a.n_px; fa.intensity = intensity; fa.la = la; fa.ca = ca;
-  if (which < 0 || which == 1)
-    if (int rc = launch_pass(PM_STATS, in_dtype, out_dtype, a, nb, s)) return rc;       // tonemap.py:147-149
-  if (which < 0)
-    if (int rc = finalize(FIN_STATS, fa, s)) return rc;
-  if (which < 0 || which == 2)
-    if (int rc = launch_pass(PM_RH_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;   // :150,153
-  if (which < 0)
-    if (int rc = finalize(FIN_BOUNDS2, fa, s)) return rc;
-  if (which < 0 || which == 3)
-    if (int rc = launch_pass(PM_RH_STORE, in_dtype, out_dtype, a, nb, s)) return rc;    // :154
+  // measurement aid: MI_ISP_PULL_DEBUG=0 runs single passes (which > 0) on the scalars a full run left
+  // in FrameParams, without the pulled finalize
+  static const char* dbg = getenv("MI_ISP_PULL_DEBUG");
+  const int no_pull = (dbg && which > 0 && dbg[0] == '0') ? -1 : 0;
+  const int dbg_bits = (dbg && which > 0 && dbg[0] > '0') ? (dbg[0] - '0') << 8 : 0;
+  if (which < 0 || which == 1) {                                                      // tonemap.py:147-149
+    PassArgs p1 = a;
+    p1.partials = stats_part; p1.part_stride = TAIL_STRIDE;
+    p1.pull_mode = no_pull ? -1 : FIN_BOUNDS | dbg_bits; p1.pull_partials = bounds.partials; p1.pull_stride = bounds.stride;
+    p1.pull_n = (dbg_bits & 0x200) ? 0 : bounds.n; p1.pull_bounds_post = bounds.bounds_post;
+    if (int rc = launch_pass(PM_STATS, in_dtype, out_dtype, p1, nb, s)) return rc;
+  }
+  if (which < 0 || which == 2) {                                                      // :150,153
+    PassArgs p2 = a;
+    p2.partials = bounds2_part; p2.part_stride = TAIL_STRIDE;
+    p2.pull_mode = no_pull ? -1 : FIN_STATS | dbg_bits; p2.pull_partials = stats_part; p2.pull_stride = TAIL_STRIDE; p2.pull_n = (dbg_bits & 0x200) ? 0 : nb;
+    if (int rc = launch_pass(PM_RH_MINMAX, in_dtype, out_dtype, p2, nb, s)) return rc;
+  }
+  if (which < 0 || which == 3) {                                                      // :154
+    PassArgs p3 = a;
+    p3.pull_mode = no_pull ? -1 : FIN_BOUNDS2 | dbg_bits; p3.pull_partials = bounds2_part; p3.pull_stride = TAIL_STRIDE; p3.pull_n = (dbg_bits & 0x200) ? 0 : nb;
+    if (int rc = launch_pass(PM_RH_STORE, in_dtype, out_dtype, p3, nb, s)) return rc;
+  }
   return 0;
 }
 }  // namespace ew
@@ -1087,10 +1234,8 @@ extern "C" int mi_isp_tonemap_linear(const void* src, void* dst, int H, int W, i
   a.gamma_inv = 1.0f / gamma;                      // tonemap.py:16: 1/gamma evaluated in f32
   a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
   const int nb = pass_blocks(a.n_px, cap);
-  if (int rc = launch_pass(PM_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;
-  FinArgs fa = {};
-  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
-  if (int rc = finalize(FIN_BOUNDS, fa, s)) return rc;
+  if (int rc = launch_pass(PM_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;       // tonemap.py:23
+  a.pull_mode = FIN_BOUNDS; a.pull_partials = partials; a.pull_stride = cap; a.pull_n = nb; a.fp_w = fp;
   return launch_pass(PM_LINEAR_STORE, in_dtype, out_dtype, a, nb, s);
 }
 
@@ -1108,14 +1253,8 @@ extern "C" int mi_isp_tonemap_reinhard(const void* src, void* dst, int H, int W,
   a.gamma_inv = 1.0f / gamma; a.la = light_adapt; a.ca = color_adapt;
   a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
   const int nb = pass_blocks(a.n_px, cap);
-  FinArgs fa = {};
-  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp;
-  fa.n_px = (float)a.n_px; fa.intensity = intensity; fa.la = light_adapt; fa.ca = color_adapt;
   if (int rc = launch_pass(PM_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;      // tonemap.py:146
-  if (int rc = finalize(FIN_BOUNDS, fa, s)) return rc;
-  if (int rc = launch_pass(PM_STATS, in_dtype, out_dtype, a, nb, s)) return rc;       // :147-149
-  if (int rc = finalize(FIN_STATS, fa, s)) return rc;
-  if (int rc = launch_pass(PM_RH_MINMAX, in_dtype, out_dtype, a, nb, s)) return rc;   // :150,153
-  if (int rc = finalize(FIN_BOUNDS2, fa, s)) return rc;
-  return launch_pass(PM_RH_STORE, in_dtype, out_dtype, a, nb, s);                      // :154
+  const PullSrc bounds = {partials, cap, nb, 0};
+  return tonemap_reinhard_tail(src, dst, H, W, in_dtype, out_dtype, gamma, intensity, light_adapt, color_adapt, fp,
+                               -1, bounds, s);
 }

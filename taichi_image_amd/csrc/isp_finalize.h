@@ -29,6 +29,16 @@ struct FinArgs {
   int bounds_post;      // FIN_BOUNDS: 0 = bounds are final; 1 = clamp to [0,1]; 2 = clamp, then round to f16
 };
 
+// FrameParams entries a stateless finalize mode writes (what a pulled finalize publishes)
+MI_DEV constexpr bool finalize_writes(int mode, int i) {
+  return mode == FIN_BOUNDS ? (i == FP_LO || i == FP_HI || i == FP_INV)
+         : mode == FIN_BOUNDS2 ? (i == FP_LO2 || i == FP_HI2 || i == FP_INV2)
+         : mode == FIN_STATS ? (i == FP_BMIN || i == FP_BMAX || i == FP_LMEAN || i == FP_GMEAN ||
+                                (i >= FP_RMEAN && i < FP_RMEAN + 3) || i == FP_MAPKEY || i == FP_EI ||
+                                (i >= FP_MEAN3 && i < FP_MEAN3 + 3))
+                             : false;
+}
+
 // tot: row 0 = min, row 1 = max, rows 2..6 = sums (fp64) over all blocks.  One thread runs this.
 MI_DEV void finalize_scalars(int mode, const FinArgs& a, const double* tot) {
   float lo = (float)tot[0], hi = (float)tot[1];

@@ -80,9 +80,10 @@ struct Params {
   float out_scale;        // scale_factor of the output dtype
   float gamma_inv, la, ca;
   int debug_skip;         // measurement aid: bit 0 skips the fill, bit 1 skips the strip compute
-  // The eight distinct demosaic weights / 16, as kernel arguments on purpose: they live in SGPRs
-  // and every tap is a 4-byte v_fmac_f32 v, s, v.  As literals each FMA would carry a 32-bit
-  // constant (8 bytes) and the strip would run at the 8-byte instruction-fetch rate (~0.55x).
+  // The eight distinct demosaic weights / 16 for the fused resize kernel (isp_resize_tile.h).  The
+  // tile kernel uses literal weights instead: measured on gfx950 (scratch/issue_bench.hip), a VALU
+  // instruction with an SGPR operand issues at half the rate of one with VGPR / literal operands
+  // (v_fmac_f32 v, s, v: 0.57 wave-instr/ns/SIMD; v_fmac_f32 v, literal, v: 0.95).
   float wq[8];
 };
 
@@ -109,6 +110,35 @@ __device__ constexpr int8_t KW[4][13][3] = {
      {8, 0, 0}, {-2, 0, 1}, {-2, 0, -2}, {0, 0, 8}, {-2, 0, -2}, {1, 0, -2}},
     {{-3, -2, 0}, {4, 0, 0}, {0, 4, 0}, {4, 0, 0}, {-3, -2, 0}, {0, 4, 0}, {12, 8, 16},
      {0, 4, 0}, {-3, -2, 0}, {4, 0, 0}, {0, 4, 0}, {4, 0, 0}, {-3, -2, 0}}};
+
+// In-bounds weight sums of a border pixel (the `t` of bayer.py:143-149), tabulated at compile time:
+// entry [kernel][row mask][col mask] packs t for R, G, B as three signed bytes, where bit (d + 2) of a
+// mask says that offset d in {-2..2} is inside the image.  The sums are small integers (units of 1/16).
+struct BorderTable { uint32_t t[4][32][32]; };
+constexpr BorderTable make_border_table() {
+  constexpr int DR[13] = {-2, -1, -1, -1, 0, 0, 0, 0, 0, 1, 1, 1, 2};
+  constexpr int DC[13] = {0, -1, 0, 1, -2, -1, 0, 1, 2, -1, 0, 1, 0};
+  BorderTable b = {};
+  for (int k = 0; k < 4; ++k)
+    for (int rm = 0; rm < 32; ++rm)
+      for (int cm = 0; cm < 32; ++cm) {
+        int t[3] = {0, 0, 0};
+        for (int tap = 0; tap < 13; ++tap)
+          if (((rm >> (DR[tap] + 2)) & 1) && ((cm >> (DC[tap] + 2)) & 1))
+            for (int ch = 0; ch < 3; ++ch) t[ch] += KW[k][tap][ch];
+        b.t[k][rm][cm] = (uint32_t)(t[0] & 0xFF) | ((uint32_t)(t[1] & 0xFF) << 8) | ((uint32_t)(t[2] & 0xFF) << 16);
+      }
+  return b;
+}
+__device__ constexpr BorderTable BORDER_T = make_border_table();
+
+// 5-bit mask of the offsets d in {-2..2} for which x + d lies in [0, n)
+MI_DEV int inside_mask(int x, int n) {
+  int m = 0;
+#pragma unroll
+  for (int d = -2; d <= 2; ++d) m |= (x + d >= 0 && x + d < n) ? 1 << (d + 2) : 0;
+  return m;
+}
 
 // ---------------------------------------------------------------------------------------------
 // unpack helpers
@@ -319,7 +349,8 @@ MI_DEV void accumulate(const float (&wq)[8], const float (&win)[6][12], float (&
       constexpr int ch = decltype(cc)::value;
       constexpr int wi = KW[KIDX][t][ch];
       if constexpr (wi != 0) {
-        const float w = wq[wq_index(wi)];
+        constexpr float w = (float)wi * 0.0625f;      // literal operand: see the note at Params::wq
+        (void)wq;
         if (first[ch]) { acc[ch] = x * w; first[ch] = false; }      // == fma(x, w, +0)
         else if constexpr (EXACT) acc[ch] = __builtin_fmaf(x, w, acc[ch]);
         else acc[ch] = acc[ch] + x * w;
@@ -503,20 +534,29 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
       }
       if (wave_has_slow) {
         // border pixels / CFAs with scale != 1: c / (in_scale * t), correctly rounded, with
-        // c == acc * 16 exactly and t the in-bounds weight sum (16 when every tap is in bounds).
-        // Each pixel position is skipped (scalar branch) when no lane of the wave needs it, e.g.
-        // only columns 0-1 of a left-edge strip are border pixels.
+        // c == acc * 16 exactly and t the in-bounds weight sum (16 when every tap is in bounds),
+        // looked up in BORDER_T.  Each pixel position is skipped (scalar branch) when no lane of the
+        // wave needs it, e.g. only columns 0-1 of a left-edge strip are border pixels.  All lookups
+        // are issued before the first use.
+        const int rmask = inside_mask(r + i, p.H);
+        uint32_t tq[8];
         static_for<0, 8>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
-          const int rr = r + i, cc = c + k;
-          const bool need = p.in_scale != 1.f || rr < 2 || rr >= p.H - 2 || cc < 2 || cc >= p.W - 2;
+          const int cmask = inside_mask(c + k, p.W);
+          const bool need = p.in_scale != 1.f || rmask != 31 || cmask != 31;
+          tq[k] = 0x101010u;                                            // t = 16 for all channels
+          if (__builtin_amdgcn_ballot_w64(need) != 0) tq[k] = BORDER_T.t[KIDX][rmask][cmask];
+        });
+        static_for<0, 8>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const int cmask = inside_mask(c + k, p.W);
+          const bool need = p.in_scale != 1.f || rmask != 31 || cmask != 31;
           if (__builtin_amdgcn_ballot_w64(need) != 0) {
-            float t3[3];
-            border_weight<KIDX>(rr, cc, p.H, p.W, t3);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-              const float fixed = (v[3 * k + ch] * 16.f) / (p.in_scale * t3[ch]);
+              const float t = (float)(int)(int8_t)(tq[k] >> (8 * ch));
+              const float fixed = (v[3 * k + ch] * 16.f) / (p.in_scale * t);
               v[3 * k + ch] = need ? fixed : v[3 * k + ch];
             }
           }
