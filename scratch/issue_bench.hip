@@ -2,7 +2,7 @@
 // 1 wave-instr per 2.4 cycles and which at 1 per 4?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-enum { FMAC_VOP2, FMA_VOP3, FMAC_SGPR, FMA_SGPR, PK_FMA, MUL_VOP2, ADD_VOP2, FMA_VOP3_DIST, CVT, MAX_VOP2, MED3, FMAC_DEP, FMAC_LIT, FMA_VOP3_3SRC, MOV, MUL_SGPR, ADD_SGPR, AND, LSHR, BFE, LSHL_OR, PERM, CVT_F32_U32, CVT_F32_F16, CVT_UB0, MIN3, CNDMASK, ADD_U32, MAD_U24, LOGF, EXPF, RCPF, MIN_VOP2, FMAMK, MUL_LIT, MAX_SELF, PK_MUL, PK_ADD, CVT_PKRTZ, MOV_DPP };
+enum { FMAC_VOP2, FMA_VOP3, FMAC_SGPR, FMA_SGPR, PK_FMA, MUL_VOP2, ADD_VOP2, FMA_VOP3_DIST, CVT, MAX_VOP2, MED3, FMAC_DEP, FMAC_LIT, FMA_VOP3_3SRC, MOV, MUL_SGPR, ADD_SGPR, AND, LSHR, BFE, LSHL_OR, PERM, CVT_F32_U32, CVT_F32_F16, CVT_UB0, MIN3, CNDMASK, ADD_U32, MAD_U24, LOGF, EXPF, RCPF, MIN_VOP2, FMAMK, MUL_LIT, MAX_SELF, PK_MUL, PK_ADD, CVT_PKRTZ, MOV_DPP, FMA_MIX, FMA_MIX_HI, FMA_MIX_LIT, PK_MIN_F16, PK_FMA_F16, CVT_PK_F16, OR_LIT, FMAAK, SUB_LIT, MIN_LIT, MUL_INL, FMAC_INL };
 template <int KIND, int BODY>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float s0, float s1) {
   float acc[8], x[8];
@@ -57,6 +57,18 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s0, float 
         if (KIND == PK_ADD) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(pa[i]) : "v"(px[(i + u) & 3]));
         if (KIND == CVT_PKRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
         if (KIND == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == FMA_MIX) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == FMA_MIX_HI) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == FMA_MIX_LIT) asm volatile("v_fma_mix_f32 %0, %1, 0.5, %0 op_sel_hi:[1,0,0]" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == PK_MIN_F16) asm volatile("v_pk_min_f16 %0, %1, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == PK_FMA_F16) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == CVT_PK_F16) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == OR_LIT) asm volatile("v_or_b32_e32 %0, 0x4b000000, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == FMAAK) asm volatile("v_fmaak_f32 %0, %1, %0, 0x3d800000" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == SUB_LIT) asm volatile("v_subrev_f32_e32 %0, 0x4b000000, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == MIN_LIT) asm volatile("v_min_f32_e32 %0, 1.0, %0" : "+v"(acc[i]));
+        if (KIND == MUL_INL) asm volatile("v_mul_f32_e32 %0, 0.5, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == FMAC_INL) asm volatile("v_fmac_f32_e32 %0, 0.5, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
         if (KIND == MOV) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
       }
     }
@@ -82,6 +94,6 @@ template <int KIND, int BODY> void run(const char* name, int blocks, int total) 
 }
 #define ALL(KIND) run<KIND, 64>(#KIND, 2048, 16384); run<KIND, 64>(#KIND " 4 waves/SIMD", 1024, 16384);
 int main() {
-  ALL(FMAC_VOP2) ALL(FMAC_SGPR) ALL(FMAC_LIT) ALL(FMAMK) ALL(MUL_VOP2) ALL(MUL_SGPR) ALL(MUL_LIT) ALL(ADD_SGPR) ALL(MAX_VOP2) ALL(MAX_SELF) ALL(MIN_VOP2) ALL(MIN3) ALL(MED3) ALL(AND) ALL(LSHR) ALL(BFE) ALL(LSHL_OR) ALL(PERM) ALL(CVT) ALL(CVT_F32_U32) ALL(CVT_F32_F16) ALL(CVT_UB0) ALL(CVT_PKRTZ) ALL(CNDMASK) ALL(ADD_U32) ALL(MAD_U24) ALL(LOGF) ALL(EXPF) ALL(RCPF) ALL(PK_FMA) ALL(PK_MUL) ALL(PK_ADD) ALL(MOV_DPP) ALL(MOV)
+  ALL(FMA_MIX) ALL(FMA_MIX_HI) ALL(FMA_MIX_LIT) ALL(PK_MIN_F16) ALL(PK_FMA_F16) ALL(CVT_PK_F16) ALL(OR_LIT) ALL(FMAAK) ALL(SUB_LIT) ALL(MIN_LIT) ALL(MUL_INL) ALL(FMAC_INL) ALL(FMAC_LIT) ALL(MOV)
   return 0;
 }

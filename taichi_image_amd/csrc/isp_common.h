@@ -69,34 +69,48 @@ template <> struct ScaleOf<uint16_t> { static constexpr float value = 65535.f; }
 MI_DEV float nmin(float a, float b) { return fminf(a, b); }
 MI_DEV float nmax(float a, float b) { return fmaxf(a, b); }
 
-// Wave64 reductions without LDS traffic: four DPP steps fold each row of 16 lanes (the DPP
-// operand rides on the min/max/add itself), then two cross-row exchanges.  ds_bpermute-based
-// shuffles cost a dependent LDS round trip per step (12-42 of them per block here).
-template <int CTRL> MI_DEV float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+// Wave64 reductions in registers: four DPP steps fold each row of 16 lanes (every lane of a row ends
+// up with the row's result), row_bcast15 / row_bcast31 fold the four rows into lane 63, and a
+// v_readlane hands the result to every lane as a scalar.  No LDS traffic: ds_bpermute-based shuffles
+// cost a dependent LDS round trip per step (12-42 of them per block here).
+template <int CTRL, int ROW_MASK = 0xF> MI_DEV float dpp_mov(float v, float old) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xF, false));
 }
-// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
-#define MI_ROW_REDUCE(OP)                      \
-  v = OP(v, dpp_mov<0xB1>(v));                 \
-  v = OP(v, dpp_mov<0x4E>(v));                 \
-  v = OP(v, dpp_mov<0x141>(v));                \
-  v = OP(v, dpp_mov<0x140>(v));                \
-  v = OP(v, __shfl_xor(v, 16, 64));            \
-  v = OP(v, __shfl_xor(v, 32, 64));
+// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140,
+// row_bcast15 = 0x142 (rows 1 and 3 take lane 15 of the row before), row_bcast31 = 0x143 (rows 2, 3 take lane 31).
+// Lanes outside the row mask get IDENT, the identity of OP.
+#define MI_WAVE_REDUCE(OP, IDENT)                          \
+  v = OP(v, dpp_mov<0xB1>(v, v));                          \
+  v = OP(v, dpp_mov<0x4E>(v, v));                          \
+  v = OP(v, dpp_mov<0x141>(v, v));                         \
+  v = OP(v, dpp_mov<0x140>(v, v));                         \
+  v = OP(v, dpp_mov<0x142, 0xA>(v, IDENT));                \
+  v = OP(v, dpp_mov<0x143, 0xC>(v, IDENT));                \
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 MI_DEV float op_add(float a, float b) { return a + b; }
-MI_DEV float wave_min(float v) { MI_ROW_REDUCE(fminf) return v; }
-MI_DEV float wave_max(float v) { MI_ROW_REDUCE(fmaxf) return v; }
-MI_DEV float wave_sum(float v) { MI_ROW_REDUCE(op_add) return v; }
-// fp64 variant for the sums of the pulled finalize (rgb_pass_kernel prologue)
-template <int CTRL> MI_DEV double dpp_mov(double v) {
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+MI_DEV float wave_min(float v) { MI_WAVE_REDUCE(fminf, __builtin_inff()) }
+MI_DEV float wave_max(float v) { MI_WAVE_REDUCE(fmaxf, -__builtin_inff()) }
+MI_DEV float wave_sum(float v) { MI_WAVE_REDUCE(op_add, 0.f) }
+#undef MI_WAVE_REDUCE
+// fp64 sum for the pulled finalize (rgb_pass_kernel prologue): the halves ride on two DPP moves
+template <int CTRL, int ROW_MASK = 0xF> MI_DEV double dpp_mov(double v, double old) {
+  const long long b = __builtin_bit_cast(long long, v), o = __builtin_bit_cast(long long, old);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)b, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
-MI_DEV double op_add(double a, double b) { return a + b; }
-MI_DEV double wave_sum(double v) { MI_ROW_REDUCE(op_add) return v; }
-#undef MI_ROW_REDUCE
+MI_DEV double wave_sum(double v) {
+  v += dpp_mov<0xB1>(v, v);
+  v += dpp_mov<0x4E>(v, v);
+  v += dpp_mov<0x141>(v, v);
+  v += dpp_mov<0x140>(v, v);
+  v += dpp_mov<0x142, 0xA>(v, 0.0);
+  v += dpp_mov<0x143, 0xC>(v, 0.0);
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
 
 // Block reduction of up to 8 values per thread for 256-thread blocks (4 waves): each wave
 // shuffles down to one value, the per-wave results meet in LDS, thread k < NV combines them

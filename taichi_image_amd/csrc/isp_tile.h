@@ -459,9 +459,18 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 // at (row, col) is K[((row+PR)&1) + 2*((col+PC)&1)] (bayer.py:92-97,165-175):
 // RGGB (0,0), GBRG (1,0), GRBG (0,1), BGGR (1,1).
 // ---------------------------------------------------------------------------------------------
-template <class E, int PR, int PC, int EPI>
-__global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
+// HOT: the configuration of the packed-RAW pipelines, fixed at compile time so that the kernel is
+// straight-line code without the generic paths: standard 12-bit packing with aligned rows, whole
+// tiles only (W % 128 == 0, H % 32 == 0), no colour matrix, stores in the work dtype (see hot_ok).
+template <class E> constexpr int dtype_code() { return sizeof(E) == 2 ? (int)MI_F16 : (int)MI_F32; }
+template <class E, int PR, int PC, int EPI, bool HOT = false>
+__global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   constexpr bool EXACT = sizeof(E) == 2;
+  Params p = p_in;
+  if constexpr (HOT) {
+    p.src_kind = SRC_PACKED12; p.src_fast = 1; p.has_ccm = 0; p.in_scale = 1.f; p.debug_skip = 0;
+    p.vec_store = 1; p.out_dtype = dtype_code<E>(); p.out_scale = 1.f;
+  }
   __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * PITCH];
   __shared__ float red[4][8];
 
@@ -479,13 +488,14 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
   if (by >= tiles_y) by -= tiles_y;
   const int r0 = by * TILE_H, c0 = bx * TILE_W;
 
-  if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
+  if constexpr (HOT) fill_packed_fast<E>(p, lds, r0 - 2, c0 - 8);
+  else if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
   __syncthreads();
 
   const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
   const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
-  const bool active = r < p.H && c < p.W && !(p.debug_skip & 2);   // H, W even -> both rows, pixel pairs in
-  const int npx = active ? (p.W - c < 8 ? p.W - c : 8) : 0;
+  const bool active = HOT || (r < p.H && c < p.W && !(p.debug_skip & 2));   // H, W even -> both rows, pixel pairs in
+  const int npx = HOT ? 8 : (active ? (p.W - c < 8 ? p.W - c : 8) : 0);
 
   // tonemap scalars (uniform loads); unused ones are dead code per EPI
   float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f;
@@ -505,8 +515,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
   float win[6][12];
   if (active) load_window(lds, tx, ty, win);
   // a full tile with 1/2-byte outputs is stored wave-cooperatively through the (now free) tile buffer
-  const bool coop_store = STORES && p.vec_store && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W &&
-                          p.out_dtype != MI_F32 && !(p.debug_skip & 32);
+  const bool coop_store = STORES && p.out_dtype != MI_F32 &&
+                          (HOT || (p.vec_store && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W && !(p.debug_skip & 32)));
   if (STORES) __syncthreads();                          // every wave holds its window
   void* stage = lds + (threadIdx.x >> 6) * (64 * 12);   // 3 KB per wave
   if (active) {
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p) {
     // Wave-uniform predicates (scalar branches): the slow blocks below are real branches that
     // interior waves skip, not per-lane selects the compiler would flatten into the fast stream.
     const bool wave_has_slow = __builtin_amdgcn_ballot_w64(!fast) != 0 && !(p.debug_skip & 16);
-    const bool wave_all_full = __builtin_amdgcn_ballot_w64(npx != 8) == 0;
+    const bool wave_all_full = HOT || __builtin_amdgcn_ballot_w64(npx != 8) == 0;
 
     static_for<0, 2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -686,6 +696,13 @@ static inline int launch(const Params& p, int work_dtype, int pattern, int epi, 
     case MI_GBRG: return launch_gbrg(p, work_dtype, epi, stream);
     default: return launch_bggr(p, work_dtype, epi, stream);
   }
+}
+
+// may this launch use the HOT specialisation of epilogue `epi`?
+static inline bool hot_ok(const Params& p, int work_dtype, int epi) {
+  const bool stores = epi == EPI_STORE || epi == EPI_STORE_MINMAX;
+  return stores && p.src_kind == SRC_PACKED12 && p.src_fast && !p.has_ccm && p.in_scale == 1.f && p.debug_skip == 0 &&
+         p.W % TILE_W == 0 && p.H % TILE_H == 0 && p.vec_store && p.out_dtype == work_dtype && p.out_scale == 1.f;
 }
 
 static inline int num_tiles(int H, int W) {
