@@ -223,12 +223,16 @@ def main():
         live = [float(v) for v in live_us]            # in-situ averages over the timed region
         dom = int(np.argmax(live))                    # the dominant kernel = the longest data pass
         dom_us = live[dom]
-        achieved = ALG_BYTES / (dom_us * 1e-6) / 1e9
+        # algorithmic bytes per launch of each pass: pass 0 reads the packed frame and writes
+        # the f16 image, passes 1-2 read it, pass 3 reads and rewrites it
+        pass_bytes = [BYTES_IN + BYTES_OUT_F16, BYTES_OUT_F16, BYTES_OUT_F16, 2 * BYTES_OUT_F16]
+        dom_bytes = pass_bytes[dom]
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("pass0_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath))["kernels"][f"pass{dom}"]["hbm_bytes"]
             except Exception:
                 traffic = None
         line = {
@@ -245,9 +249,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": PASS_NAMES[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ALG_BYTES, "avg_launch_us": round(dom_us, 2),
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_us, 2),
                          "launches_timed": int(live_n.value), "isolated_launch_us": round(passes[dom], 2),
-                         "isolated_frac": round(ALG_BYTES / (passes[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "isolated_frac": round(dom_bytes / (passes[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels_us_live": {f"pass{k}": round(live[k], 2) for k in range(4)},
             "kernels_us_isolated": {f"pass{k}": round(passes[k], 2) for k in range(4)},
         }

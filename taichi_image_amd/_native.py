@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355_isp.so")
+# MI_ISP_LIB: an instrumented build of the same library (measurement only, e.g. scripts/tile_stamps.py)
+LIB_PATH = os.environ.get("MI_ISP_LIB") or os.path.join(_HERE, "lib", "libmi355_isp.so")
 
 MI_U8, MI_U16, MI_F16, MI_F32 = 0, 1, 2, 3
 

@@ -462,6 +462,18 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 // HOT: the configuration of the packed-RAW pipelines, fixed at compile time so that the kernel is
 // straight-line code without the generic paths: standard 12-bit packing with aligned rows, whole
 // tiles only (W % 128 == 0, H % 32 == 0), no colour matrix, stores in the work dtype (see hot_ok).
+// measurement aid (make EXTRA=-DMI_TILE_STAMPS): wave 0 of every block leaves s_memtime stamps of its
+// phases in workspace rows 2.. (32-bit, 8 per block); see scripts/tile_stamps.py
+#ifdef MI_TILE_STAMPS
+#define MI_STAMP(i)                                                                                      \
+  do {                                                                                                   \
+    if (HOT && threadIdx.x == 0)                                                                         \
+      reinterpret_cast<unsigned*>(p.partials + 2 * (size_t)p.part_stride)[blockIdx.x * 8 + (i)] =       \
+          (unsigned)__builtin_readcyclecounter();                                                        \
+  } while (0)
+#else
+#define MI_STAMP(i) do {} while (0)
+#endif
 template <class E> constexpr int dtype_code() { return sizeof(E) == 2 ? (int)MI_F16 : (int)MI_F32; }
 template <class E, int PR, int PC, int EPI, bool HOT = false>
 __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
@@ -488,9 +500,12 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   if (by >= tiles_y) by -= tiles_y;
   const int r0 = by * TILE_H, c0 = bx * TILE_W;
 
+  MI_STAMP(0);
   if constexpr (HOT) fill_packed_fast<E>(p, lds, r0 - 2, c0 - 8);
   else if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
+  MI_STAMP(1);
   __syncthreads();
+  MI_STAMP(2);
 
   const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
   const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
@@ -518,6 +533,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   const bool coop_store = STORES && p.out_dtype != MI_F32 &&
                           (HOT || (p.vec_store && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W && !(p.debug_skip & 32)));
   if (STORES) __syncthreads();                          // every wave holds its window
+  MI_STAMP(3);
   void* stage = lds + (threadIdx.x >> 6) * (64 * 12);   // 3 KB per wave
   if (active) {
     // every tap of all 16 pixels in bounds, and c / (in_scale * t) == c / 16 ?
@@ -658,6 +674,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
           }
         }
       };
+      MI_STAMP(4 + i);                                  // 4: row 0 computed, 5: row 1 computed (before their stores)
       if constexpr (EPI == EPI_RH_MINMAX || EPI == EPI_RH_STORE) {
         if (wave_all_full && rk.ca == 0.f) epilogue(std::true_type{}, std::true_type{});      // the hot path
         else if (rk.ca == 0.f) epilogue(std::false_type{}, std::true_type{});
@@ -669,6 +686,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
     });
   }
 
+  MI_STAMP(6);
   if (p.debug_skip & 4) {                       // measurement aid: no block reduction
     if (vmin + vmax + st.slog == 12345.f) p.partials[blockIdx.x] = vmin;
     return;
@@ -677,6 +695,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
     const float v[2] = {vmin, vmax};
     const int op[2] = {0, 1};
     block_reduce_store<2>(v, op, red, p.partials, p.part_stride, blockIdx.x);
+    MI_STAMP(7);
   } else if (EPI == EPI_STATS) {
     const float v[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[7] = {0, 1, 2, 2, 2, 2, 2};
