@@ -248,19 +248,27 @@ __global__ __launch_bounds__(EW_THREADS) void transform_kernel(const T* __restri
 // ---------------------------------------------------------------------------------------------
 // 8-pixel (24-element) vector IO on (H, W, 3) images
 // ---------------------------------------------------------------------------------------------
-// the 24 elements of an aligned whole group, as loaded (issued early, converted when used)
-template <class T> MI_DEV void load24_raw(const T* p, T (&t)[24]) {
-  if (sizeof(T) == 1) {
-    const uint2* s = reinterpret_cast<const uint2*>(p);
-    uint2* d = reinterpret_cast<uint2*>(t);
-    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
-  } else {
-    constexpr int N = (int)(sizeof(T) * 24 / 16);
-    const uint4* s = reinterpret_cast<const uint4*>(p);
-    uint4* d = reinterpret_cast<uint4*>(t);
+// The 24 elements of an aligned whole group as raw 16-byte (8-byte for u8) units: issued early and
+// kept opaque until used, so that the unpacking (and with it the wait for the data) stays at the use.
+template <class T> struct Raw24 { typename IoUnit<T>::type u[IoUnits<T>::value]; };
+template <class T> MI_DEV void load24_raw(const T* p, Raw24<T>& r) {
+  typedef typename IoUnit<T>::type U;
+  const U* s = reinterpret_cast<const U*>(p);
 #pragma unroll
-    for (int i = 0; i < N; ++i) d[i] = s[i];
-  }
+  for (int i = 0; i < IoUnits<T>::value; ++i) r.u[i] = s[i];
+}
+template <class T> MI_DEV void raw_to_float(const Raw24<T>& r, float (&v)[24]) {
+  // The words pass through an empty volatile asm first: without it LLVM folds the unpacking (shifts,
+  // conversions) into the loop-carried value, i.e. moves it - and the s_waitcnt for the data - up to
+  // right behind the prefetching loads, which serialises load latency and compute again.
+  uint32_t w[sizeof(r.u) / 4];
+  __builtin_memcpy(w, r.u, sizeof(w));
+#pragma unroll
+  for (size_t i = 0; i < sizeof(w) / 4; ++i) asm volatile("" : "+v"(w[i]));
+  T t[24];
+  __builtin_memcpy(t, w, sizeof(t));
+#pragma unroll
+  for (int i = 0; i < 24; ++i) v[i] = (float)t[i];
 }
 
 template <class T> MI_DEV void load24(const T* p, float (&v)[24], int npx, bool vec) {
@@ -381,25 +389,32 @@ MI_DEV void pull_finalize(const PassArgs& a, float* sh_fp, double (*sh_tot)[PASS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     sh_tot[0][wave] = (double)mn; sh_tot[1][wave] = (double)mx;
+    if (nrows == 7) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sh_tot[k + 2][wave] = sum[k];
+      for (int k = 0; k < 5; ++k) sh_tot[k + 2][wave] = sum[k];
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot[7];
-    tot[0] = sh_tot[0][0]; tot[1] = sh_tot[1][0];
-#pragma unroll
-    for (int k = 2; k < 7; ++k) tot[k] = sh_tot[k][0];
-    for (int w = 1; w < PASS_THREADS / 64; ++w) {
-      tot[0] = fmin(tot[0], sh_tot[0][w]); tot[1] = fmax(tot[1], sh_tot[1][w]);
-#pragma unroll
-      for (int k = 2; k < 7; ++k) tot[k] += sh_tot[k][w];
+  // wave 0: lane k folds row k over the waves, the rows meet in lane 0 through DPP-free readlanes
+  if (wave == 0) {
+    double r = 0.0;
+    if (lane < nrows) {
+      r = sh_tot[lane][0];
+      for (int w = 1; w < PASS_THREADS / 64; ++w)
+        r = lane == 0 ? fmin(r, sh_tot[lane][w]) : (lane == 1 ? fmax(r, sh_tot[lane][w]) : r + sh_tot[lane][w]);
     }
-    ew::FinArgs fa = {};
-    fa.fp = sh_fp; fa.n_px = a.pull_npx; fa.intensity = a.pull_intensity; fa.la = a.la; fa.ca = a.ca;
-    fa.bounds_post = a.pull_bounds_post;
-    if (!(a.pull_mode & 0x100)) {
-      ew::finalize_scalars(mode, fa, tot);
+    double tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const long long b = __builtin_bit_cast(long long, r);
+      const int lo = __builtin_amdgcn_readlane((int)b, k), hi = __builtin_amdgcn_readlane((int)(b >> 32), k);
+      tot[k] = k < nrows ? __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo) : 0.0;
+    }
+    if (lane == 0 && !(a.pull_mode & 0x100)) {
+      ew::FinArgs fa = {};
+      fa.fp = sh_fp; fa.n_px = a.pull_npx; fa.intensity = a.pull_intensity; fa.la = a.la; fa.ca = a.ca;
+      fa.bounds_post = a.pull_bounds_post;
+      ew::finalize_scalars<true>(mode, fa, tot);
     }
   }
   __syncthreads();
@@ -440,8 +455,12 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   const bool can_full = a.vec_in && (!STORES || (a.vec_out && a.transform == MI_T_NONE));
   const int64_t n_full = can_full ? (a.n_px / 8) / 64 * 64 : 0;
   // the first group's loads are in flight while the prologue folds the producer's partials
-  TI raw[24];
-  if (tid < n_full) load24_raw<TI>(src + tid * 24, raw);
+
+  constexpr int PREFETCH = 1;                       // deeper (2-3 groups) measured slower on gfx950
+  Raw24<TI> raws[PREFETCH];
+#pragma unroll
+  for (int d = 0; d < PREFETCH; ++d)
+    if (tid + d * stride < n_full) load24_raw<TI>(src + (tid + d * stride) * 24, raws[d]);
 
   if constexpr (PULL_FIN >= 0) {
     if (pulled) pull_finalize<PULL_FIN>(a, sh_fp, sh_tot);
@@ -470,7 +489,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   // One group = 8 pixels = 24 elements.  FULL: the wave's 64 groups are whole, aligned and
   // contiguous, no orientation transform -> wave-contiguous IO through LDS and straight-line code
   // without per-pixel tests.  CA0: color_adapt == 0 (one pow/px).
-  auto group = [&](auto full_c, auto ca0_c, int64_t g) {
+  auto group = [&](auto full_c, auto ca0_c, int64_t g, Raw24<TI>& raw) {
     constexpr bool FULL = decltype(full_c)::value;
     constexpr bool CA0 = decltype(ca0_c)::value;
     const int64_t px0 = g * 8;
@@ -480,9 +499,8 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
     // loads through LDS for reads; the stores below do go through LDS (3.7 -> 6.2 TB/s)
     if constexpr (FULL) {
       // software pipeline: this group was loaded one iteration ago; start the next one now
-#pragma unroll
-      for (int i = 0; i < 24; ++i) v[i] = (float)raw[i];
-      if (g + stride < n_full) load24_raw<TI>(src + (g + stride) * 24, raw);
+      raw_to_float<TI>(raw, v);
+      if (g + PREFETCH * stride < n_full) load24_raw<TI>(src + (g + PREFETCH * stride) * 24, raw);
     } else {
       load24<TI>(src + px0 * 3, v, npx, a.vec_in);
     }
@@ -589,10 +607,14 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   };
 
   if (rk.ca == 0.f) {
-    for (int64_t g = tid; g < n_full; g += stride) group(std::true_type{}, std::true_type{}, g);
-    for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::true_type{}, g);
+    for (int64_t g = tid; g < n_full; g += PREFETCH * stride) {
+#pragma unroll
+      for (int d = 0; d < PREFETCH; ++d)
+        if (g + d * stride < n_full) group(std::true_type{}, std::true_type{}, g + d * stride, raws[d]);
+    }
+    for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::true_type{}, g, raws[0]);
   } else {
-    for (int64_t g = tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, g);
+    for (int64_t g = tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, g, raws[0]);
   }
 
   if constexpr (PULL_FIN >= 0) {
