@@ -2,7 +2,7 @@
 // 1 wave-instr per 2.4 cycles and which at 1 per 4?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-enum { FMAC_VOP2, FMA_VOP3, FMAC_SGPR, FMA_SGPR, PK_FMA, MUL_VOP2, ADD_VOP2, FMA_VOP3_DIST, CVT, MAX_VOP2, MED3, FMAC_DEP, FMAC_LIT, FMA_VOP3_3SRC, MOV, MUL_SGPR, ADD_SGPR, AND, LSHR, BFE, LSHL_OR, PERM, CVT_F32_U32, CVT_F32_F16, CVT_UB0, MIN3, CNDMASK, ADD_U32, MAD_U24, LOGF, EXPF, RCPF, MIN_VOP2, FMAMK, MUL_LIT, MAX_SELF, PK_MUL, PK_ADD, CVT_PKRTZ, MOV_DPP, FMA_MIX, FMA_MIX_HI, FMA_MIX_LIT, PK_MIN_F16, PK_FMA_F16, CVT_PK_F16, OR_LIT, FMAAK, SUB_LIT, MIN_LIT, MUL_INL, FMAC_INL };
+enum { FMAC_VOP2, FMA_VOP3, FMAC_SGPR, FMA_SGPR, PK_FMA, MUL_VOP2, ADD_VOP2, FMA_VOP3_DIST, CVT, MAX_VOP2, MED3, FMAC_DEP, FMAC_LIT, FMA_VOP3_3SRC, MOV, MUL_SGPR, ADD_SGPR, AND, LSHR, BFE, LSHL_OR, PERM, CVT_F32_U32, CVT_F32_F16, CVT_UB0, MIN3, CNDMASK, ADD_U32, MAD_U24, LOGF, EXPF, RCPF, MIN_VOP2, FMAMK, MUL_LIT, MAX_SELF, PK_MUL, PK_ADD, CVT_PKRTZ, MOV_DPP, FMA_MIX, FMA_MIX_HI, FMA_MIX_LIT, PK_MIN_F16, PK_FMA_F16, CVT_PK_F16, OR_LIT, FMAAK, SUB_LIT, MIN_LIT, MUL_INL, FMAC_INL, CND_VCC, CND_SGPR, CMP_VCC, CMP_SGPR, CMP_CND, MIN_U32, MAX_I32, MIN3_U32, CVT_F16_SDWA, BFI, LSHL_ADD, ADD3, AND_OR, XAD, CMP_CND3, CND_S64, CND_S64_ALT };
 template <int KIND, int BODY>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float s0, float s1) {
   float acc[8], x[8];
@@ -14,6 +14,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s0, float 
   for (int i = 0; i < 8; ++i) pa[i] = f2{acc[i], acc[i] + 1};
 #pragma unroll
   for (int i = 0; i < 4; ++i) px[i] = f2{x[i], x[i + 4]};
+  unsigned long long mask = __builtin_amdgcn_ballot_w64(threadIdx.x & 1), mask2 = __builtin_amdgcn_ballot_w64(threadIdx.x & 2);
+  asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(acc[0]), "v"(x[1]) : "vcc");
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < BODY / 8; ++u) {
@@ -69,6 +71,21 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s0, float 
         if (KIND == MIN_LIT) asm volatile("v_min_f32_e32 %0, 1.0, %0" : "+v"(acc[i]));
         if (KIND == MUL_INL) asm volatile("v_mul_f32_e32 %0, 0.5, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
         if (KIND == FMAC_INL) asm volatile("v_fmac_f32_e32 %0, 0.5, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == CND_VCC) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(x[(i + u) & 7]) : );
+        if (KIND == CMP_VCC) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(acc[i]), "v"(x[(i + u) & 7]) : "vcc");
+        if (KIND == CMP_CND) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(x[(i + u) & 7]) : "vcc");
+        if (KIND == MIN_U32) asm volatile("v_min_u32_e32 %0, %1, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == MAX_I32) asm volatile("v_max_i32_e32 %0, %1, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == MIN3_U32) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == CVT_F16_SDWA) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == BFI) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
+        if (KIND == ADD3) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == AND_OR) asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == XAD) asm volatile("v_xad_u32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x[(i + u) & 7]), "v"(x[(i + 3) & 7]));
+        if (KIND == CMP_CND3) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %0, %1, %0, vcc\n v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(x[(i + u) & 7]) : "vcc");
+        if (KIND == CND_S64) { float tmp; asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(tmp) : "v"(acc[i]), "v"(x[(i + u) & 7]), "s"(mask)); acc[i] = tmp; }
+        if (KIND == CND_S64_ALT) { float tmp; asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(tmp) : "v"(acc[i]), "v"(x[(i + u) & 7]), "s"((i & 1) ? mask : mask2)); acc[i] = tmp; }
         if (KIND == MOV) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(acc[i]) : "v"(x[(i + u) & 7]));
       }
     }
@@ -76,7 +93,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s0, float 
   float s = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i] + pa[i].x + pa[i].y;
-  out[blockIdx.x * 256 + threadIdx.x] = s;
+  out[blockIdx.x * 256 + threadIdx.x] = s + (float)((mask ^ mask2) & 1);
 }
 template <int KIND, int BODY> void run(const char* name, int blocks, int total) {
   float* out; (void)hipMalloc(&out, blocks * 256 * 4);
@@ -94,6 +111,6 @@ template <int KIND, int BODY> void run(const char* name, int blocks, int total) 
 }
 #define ALL(KIND) run<KIND, 64>(#KIND, 2048, 16384); run<KIND, 64>(#KIND " 4 waves/SIMD", 1024, 16384);
 int main() {
-  ALL(FMA_MIX) ALL(FMA_MIX_HI) ALL(FMA_MIX_LIT) ALL(PK_MIN_F16) ALL(PK_FMA_F16) ALL(CVT_PK_F16) ALL(OR_LIT) ALL(FMAAK) ALL(SUB_LIT) ALL(MIN_LIT) ALL(MUL_INL) ALL(FMAC_INL) ALL(FMAC_LIT) ALL(MOV)
+  ALL(CND_VCC) ALL(CMP_CND) ALL(CMP_CND3) ALL(CND_S64) ALL(CND_S64_ALT) ALL(MOV)
   return 0;
 }

@@ -50,7 +50,8 @@ MI_DEV int quad_origin(int i, float s, int n) {
 }
 
 // One demosaiced source pixel (bayer.py:138-155) at run-time position (rr, cc): kernel KIDX,
-// taps from the LDS region whose element (0, 0) is image (rb, cb).
+// taps from the LDS region whose element (0, 0) is image (rb, cb).  The weights are literals:
+// an SGPR operand would halve the issue rate of every FMA (scratch/issue_bench.hip).
 template <int KIDX, bool EXACT>
 MI_DEV void demosaic_at(const Params& p, const float* lds, int rb, int cb, int rr, int cc, float (&rgb)[3]) {
   const float* ctr = lds + (rr - rb) * PITCH + (cc - cb);
@@ -63,7 +64,7 @@ MI_DEV void demosaic_at(const Params& p, const float* lds, int rb, int cb, int r
       constexpr int ch = decltype(chc)::value;
       constexpr int wi = KW[KIDX][t][ch];
       if constexpr (wi != 0) {
-        const float w = p.wq[tile::wq_index(wi)];
+        constexpr float w = (float)wi * 0.0625f;
         if (first[ch]) { acc[ch] = x * w; first[ch] = false; }
         else if constexpr (EXACT) acc[ch] = __builtin_fmaf(x, w, acc[ch]);
         else acc[ch] = acc[ch] + x * w;
@@ -91,10 +92,19 @@ MI_DEV void demosaic_at(const Params& p, const float* lds, int rb, int cb, int r
   for (int ch = 0; ch < 3; ++ch) rgb[ch] = clamp01(acc[ch]);
 }
 
-template <class E, int PR, int PC>
-__global__ __launch_bounds__(THREADS) void resize_tile_kernel(const RParams rp) {
+// u / n for 0 <= u < 2^16 and 1 <= n <= 64 without an integer division
+MI_DEV int small_div(int u, float inv_n) { return (int)(((float)u + 0.5f) * inv_n); }
+
+constexpr int FILL_NIT = (R_CAP * (C_CAP / 8) + THREADS - 1) / THREADS;
+
+// HOT: 12-bit standard packing with aligned rows, no colour matrix (the configuration of
+// Camera16/32.load_packed12), fixed at compile time; see tile::tile_kernel.
+template <class E, int PR, int PC, bool HOT = false>
+__global__ __launch_bounds__(THREADS) void resize_tile_kernel(const RParams rp_in) {
   constexpr bool EXACT = sizeof(E) == 2;
-  const Params& p = rp.t;
+  RParams rp = rp_in;
+  Params& p = rp.t;
+  if constexpr (HOT) { p.src_kind = tile::SRC_PACKED12; p.src_fast = 1; p.has_ccm = 0; p.in_scale = 1.f; }
   __shared__ __attribute__((aligned(16))) float lds[R_CAP * PITCH];
 
   const int tiles_x = (rp.Wd + DW - 1) / DW;
@@ -109,15 +119,46 @@ __global__ __launch_bounds__(THREADS) void resize_tile_kernel(const RParams rp) 
   const int cb = ((c_lo + 8192) & ~7) - 8192;                                    // floor to a multiple of 8
   const int ce = quad_origin(c1d, rp.s1, p.W) + 1 + 2;
   const int nrows = re - rb + 1, nunits = (ce - cb) / 8 + 1;                     // <= R_CAP, <= C_CAP / 8 (host-checked)
+  const float inv_units = 1.0f / (float)nunits;
 
   // ---- fill: unpack the region into LDS (zeros outside the image) -----------------------------
-  {
+  if constexpr (HOT) {
+    // all loads of the lane first (one memory latency per tile), then unpack
+    const uint8_t* base = static_cast<const uint8_t*>(p.src);
+    const size_t pitch = (size_t)p.W * 3 / 2;
+    uint32_t raw[FILL_NIT][3];
+#pragma unroll
+    for (int it = 0; it < FILL_NIT; ++it) {
+      const int u = threadIdx.x + it * THREADS;
+      const int lr = small_div(u, inv_units), lu = u - lr * nunits;
+      const int r = rb + lr, c = cb + lu * 8;
+      raw[it][0] = raw[it][1] = raw[it][2] = 0;
+      if (u < nrows * nunits && r >= 0 && r < p.H && c >= 0 && c < p.W) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + (size_t)c * 3 / 2);
+        raw[it][0] = q[0]; raw[it][1] = q[1]; raw[it][2] = q[2];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < FILL_NIT; ++it) {
+      const int u = threadIdx.x + it * THREADS;
+      if (u >= nrows * nunits) continue;
+      const int lr = small_div(u, inv_units), lu = u - lr * nunits;
+      uint32_t v[8];
+      tile::unpack12x8(raw[it][0], raw[it][1], raw[it][2], false, v);
+      float out[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = tile::decode_scaled<E>(v[i], p.k_decode);
+      float* d = lds + lr * PITCH + lu * 8;
+      *reinterpret_cast<float4*>(d) = make_float4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    }
+  } else {
     const uint8_t* base = static_cast<const uint8_t*>(p.src);
     const bool is16 = p.src_kind == tile::SRC_PACKED16;
     const bool ids = p.src_kind == tile::SRC_PACKED12_IDS;
     const size_t pitch = is16 ? (size_t)p.W * 2 : (size_t)p.W * 3 / 2;
     for (int u = threadIdx.x; u < nrows * nunits; u += THREADS) {
-      const int lr = u / nunits, lu = u - lr * nunits;
+      const int lr = small_div(u, inv_units), lu = u - lr * nunits;
       const int r = rb + lr, c = cb + lu * 8;
       uint32_t v[8];
 #pragma unroll
@@ -162,57 +203,85 @@ __global__ __launch_bounds__(THREADS) void resize_tile_kernel(const RParams rp) 
   }
   __syncthreads();
 
-  // ---- 4 destination pixels per lane: consecutive lanes = consecutive columns of one row -------
-  E* dst = static_cast<E*>(p.dst);
-#pragma unroll 1
-  for (int j = 0; j < DW * DH / THREADS; ++j) {
-    const int idx = threadIdx.x + j * THREADS;
-    const int r = r0d + idx / DW, c = c0d + (idx & (DW - 1));
-    const bool live = r < rp.Hd && c < rp.Wd;
-    // dead lanes compute a valid in-tile pixel (the ballots below are wave-wide) and skip the store
-    const int rr_d = live ? r : r0d, cc_d = live ? c : c0d;
-    // sample_bilinear (interpolate.py:24-34)
-    const float pr = (float)rr_d / rp.s0, pc = (float)cc_d / rp.s1;
-    const int ir = (int)pr, ic = (int)pc;
-    const float fr = pr - (float)ir, fc = pc - (float)ic;
-    const int ra = min(ir, p.H - 1), rbm = min(ir + 1, p.H - 1);                  // index_clamped (:20-21)
+  // ---- every lane: 4 consecutive destination pixels of one row (16 lanes across, 16 rows) --------
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int r = r0d + ty, cbase = c0d + 4 * tx;
+  // dead lanes compute a valid in-tile pixel (the ballots in demosaic_at are wave-wide) and skip the store
+  const int rr_d = r < rp.Hd ? r : r0d;
+  // sample_bilinear (interpolate.py:24-34), row part
+  const float pr = (float)rr_d / rp.s0;
+  const int ir = (int)pr;
+  const float fr = pr - (float)ir;
+  const int ra = min(ir, p.H - 1), rbm = min(ir + 1, p.H - 1);                    // index_clamped (:20-21)
+  const int qr = min(ir, p.H - 2);                                                // the 2x2 quad holding all taps
+  const int par_r = (qr + PR) & 1;
+  const int row0 = qr + par_r, row1 = qr + 1 - par_r;                             // (row + PR) & 1 == 0 / 1
+  const bool ra1 = ((ra + PR) & 1) != 0, rb1 = ((rbm + PR) & 1) != 0;            // site parity of each row tap
+  float o[4][3];
+  static_for<0, 4>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int c = cbase + j;
+    const int cc_d = (r < rp.Hd && c < rp.Wd) ? c : c0d;
+    const float pc = (float)cc_d / rp.s1;
+    const int ic = (int)pc;
+    const float fc = pc - (float)ic;
     const int ca = min(ic, p.W - 1), cbm = min(ic + 1, p.W - 1);
-    const int qr = min(ir, p.H - 2), qc = min(ic, p.W - 2);                      // the 2x2 quad holding all taps
-    // the quad's row / column with site parity 0 and 1
-    const int par_r = (qr + PR) & 1, par_c = (qc + PC) & 1;
-    const int row0 = qr + par_r, row1 = qr + 1 - par_r;                           // (row + PR) & 1 == 0 / 1
+    const int qc = min(ic, p.W - 2);
+    const int par_c = (qc + PC) & 1;
     const int col0 = qc + par_c, col1 = qc + 1 - par_c;
     float P[2][2][3];                                                            // [row parity][col parity][rgb]
     demosaic_at<0, EXACT>(p, lds, rb, cb, row0, col0, P[0][0]);
     demosaic_at<1, EXACT>(p, lds, rb, cb, row1, col0, P[1][0]);
     demosaic_at<2, EXACT>(p, lds, rb, cb, row0, col1, P[0][1]);
     demosaic_at<3, EXACT>(p, lds, rb, cb, row1, col1, P[1][1]);
-    // the reference stores the full-resolution RGB in the work dtype (scale 1) before resizing
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) P[a][b][ch] = (float)cast_out<E>(P[a][b][ch]);
-    const bool ra1 = ((ra + PR) & 1) != 0, rb1 = ((rbm + PR) & 1) != 0;          // site parity of each tap
-    const bool ca1 = ((ca + PC) & 1) != 0, cb1 = ((cbm + PC) & 1) != 0;
-    float o[3];
+    const bool ca1 = ((ca + PC) & 1) != 0, cb1 = ((cbm + PC) & 1) != 0;          // site parity of each column tap
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float p00 = P[0][0][ch], p10 = P[1][0][ch], p01 = P[0][1][ch], p11 = P[1][1][ch];
-      const float ta_ca = ra1 ? (ca1 ? p11 : p10) : (ca1 ? p01 : p00);           // src[ra, ca]
-      const float tb_ca = rb1 ? (ca1 ? p11 : p10) : (ca1 ? p01 : p00);           // src[rb, ca]
-      const float ta_cb = ra1 ? (cb1 ? p11 : p10) : (cb1 ? p01 : p00);           // src[ra, cb]
-      const float tb_cb = rb1 ? (cb1 ? p11 : p10) : (cb1 ? p01 : p00);           // src[rb, cb]
-      const float y1 = ta_ca * (1.0f - fr) + tb_ca * fr;                         // mix over rows (:28-33)
-      const float y2 = ta_cb * (1.0f - fr) + tb_cb * fr;
-      o[ch] = y1 * (1.0f - fc) + y2 * fc;                                        // intensity scale 1 (same dtype)
+      // the reference stores the full-resolution RGB in the work dtype (scale 1) before resizing
+      const float p00 = (float)cast_out<E>(P[0][0][ch]), p10 = (float)cast_out<E>(P[1][0][ch]);
+      const float p01 = (float)cast_out<E>(P[0][1][ch]), p11 = (float)cast_out<E>(P[1][1][ch]);
+      // rows first: the values at rows ra / rb for each column parity, mixed over rows (:28-33); then
+      // the column taps pick their parity.  Same operations on the same operands as mixing
+      // src[ra, ca], src[rb, ca] and src[ra, cb], src[rb, cb] directly, with half the selects.
+      const float a0 = ra1 ? p10 : p00, b0 = rb1 ? p10 : p00;                    // column parity 0
+      const float a1 = ra1 ? p11 : p01, b1 = rb1 ? p11 : p01;                    // column parity 1
+      const float m0 = a0 * (1.0f - fr) + b0 * fr;
+      const float m1 = a1 * (1.0f - fr) + b1 * fr;
+      const float y1 = ca1 ? m1 : m0;                                            // column ca
+      const float y2 = cb1 ? m1 : m0;                                            // column cb
+      o[j][ch] = y1 * (1.0f - fc) + y2 * fc;                                     // intensity scale 1 (same dtype)
     }
-    if (live) {
-      E* q = dst + ((size_t)r * rp.Wd + c) * 3;
-      q[0] = cast_out<E>(o[0]); q[1] = cast_out<E>(o[1]); q[2] = cast_out<E>(o[2]);
+  });
+  if (r < rp.Hd) {
+    E* dst = static_cast<E*>(p.dst) + ((size_t)r * rp.Wd + cbase) * 3;
+    E t[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) t[3 * j + ch] = cast_out<E>(o[j][ch]);
+    // 4 px = 24 / 48 contiguous bytes: vector stores when the row pitch keeps them aligned
+    const bool vec = cbase + 4 <= rp.Wd && (rp.Wd & 3) == 0 && ((uintptr_t)p.dst & 15) == 0;
+    if (vec) {
+      if constexpr (sizeof(E) == 2) {
+        const uint2* sv = reinterpret_cast<const uint2*>(t);
+        uint2* dv = reinterpret_cast<uint2*>(dst);
+        dv[0] = sv[0]; dv[1] = sv[1]; dv[2] = sv[2];
+      } else {
+        const uint4* sv = reinterpret_cast<const uint4*>(t);
+        uint4* dv = reinterpret_cast<uint4*>(dst);
+        dv[0] = sv[0]; dv[1] = sv[1]; dv[2] = sv[2];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (cbase + j < rp.Wd) { dst[3 * j] = t[3 * j]; dst[3 * j + 1] = t[3 * j + 1]; dst[3 * j + 2] = t[3 * j + 2]; }
     }
   }
+}
+
+static inline bool hot_ok(const RParams& rp) {
+  const Params& p = rp.t;
+  return p.src_kind == tile::SRC_PACKED12 && p.src_fast && !p.has_ccm && p.in_scale == 1.f;
 }
 
 static inline int num_tiles(int Hd, int Wd) { return ((Wd + DW - 1) / DW) * ((Hd + DH - 1) / DH); }
