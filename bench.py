@@ -97,6 +97,11 @@ def cpu_baseline(packed_frame: np.ndarray):
                       f"(oracle/isp_oracle.py), host has {ncores} cores"}
 
 
+def reduce_device(device):
+    """Where the max-over-ranks timing tensor lives: the GPU under RCCL, the host in a gloo rehearsal."""
+    return torch.device("cpu") if os.environ.get("MI_ISP_BENCH_BACKEND", "nccl") == "gloo" else device
+
+
 def isp_workload(args, rank, world, device):
     """Configs 3 / 5: the stateful Camera16 chain on `--frames` cameras per rank per step."""
     import torch.distributed as dist
@@ -126,7 +131,7 @@ def isp_workload(args, rank, world, device):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -170,12 +175,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    device = torch.device("cuda", local_rank)
+    # MI_ISP_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than
+    # ranks (ranks share devices, timing tensors go through the host); the real runs use RCCL
+    backend = os.environ.get("MI_ISP_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from taichi_image_amd import synthetic
     from taichi_image_amd.pipeline import BatchPipeline
@@ -211,7 +222,7 @@ def main():
     _native.check(_native.lib().mi_isp_profile_collect(live_us, ctypes.byref(live_n)))
     _native.check(_native.lib().mi_isp_profile_enable(0, 1))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
