@@ -75,6 +75,16 @@ int mi_isp_demosaic(const void* cfa_dev, void* rgb_dev, int H, int W, int in_dty
 int mi_isp_mosaic(const void* rgb_dev, void* cfa_dev, int H, int W, int dtype, int pattern,
                   void* stream);
 
+/* ---- color/yuv_420.py (the step after the path) ----------------------------------------- */
+/* rgb_yuv420_kernel (yuv_420.py:39-66): (H, W, 3) RGB -> (H * 3 / 2, W) planar 4:2:0: rows [0, H) = Y,
+ * then two (H/2, W/2) planes, plane 0 = yuv.z, plane 1 = yuv.y.  H, W even.  Reference quirks kept:
+ * the matrix sees rgb.bgr, and clamp(0, 1, x) is min(1, x). */
+int mi_isp_rgb_to_yuv420(const void* rgb_dev, void* yuv_dev, int H, int W, int in_dtype, int out_dtype,
+                         void* stream);
+/* yuv420_rgb_kernel (yuv_420.py:68-92): the inverse; H, W are the RGB image's. */
+int mi_isp_yuv420_to_rgb(const void* yuv_dev, void* rgb_dev, int H, int W, int in_dtype, int out_dtype,
+                         void* stream);
+
 /* ---- interpolate.py -------------------------------------------------------------------- */
 /* bilinear_kernel (interpolate.py:19-34,59-86): dst (Hd,Wd,3) <- src (Hs,Ws,3);
  * p = (r/scale0, c/scale1), clamp-to-edge taps, out * scale(out)/scale(in). */

@@ -547,3 +547,67 @@ def isp_load_packed16(packed, work="f16", pattern=RGGB, correct_colors=None, res
     rgb = bayer_to_rgb(cfa, pattern, correct_colors)
     sz = isp_output_size(rgb.shape[0], rgb.shape[1], resize_width, scale)
     return rgb if sz is None else resize_bilinear(rgb, sz[0], sz[1])
+
+
+# --------------------------------------------------------------------------------------
+# color/yuv_420.py  (the step after the path)
+# --------------------------------------------------------------------------------------
+# yuv_420.py:12-16: the matrix is named for BGR input but rgb_YCrCb feeds it rgb.bgr (:26-27), so
+# Y = 0.299 B + 0.587 G + 0.114 R for an RGB image -- reproduced as written.
+YCRCB_T_BGR = np.array([[0.299, 0.587, 0.114], [-0.168736, -0.331264, 0.5], [0.5, -0.418688, -0.081312]])
+BGR_T_YCRCB = np.linalg.inv(YCRCB_T_BGR)          # yuv_420.py:18 (Python-scope inverse, float64)
+
+
+def _matvec3(m, v0, v1, v2):
+    """Taichi mat @ vec in f32: (m0*v0 + m1*v1) + m2*v2 per row."""
+    m = m.astype(f32)
+    return [(m[i, 0] * v0 + m[i, 1] * v1) + m[i, 2] * v2 for i in range(3)]
+
+
+def _clamp_quirk(x):
+    """tm.clamp(0, 1, x) (yuv_420.py:54,57,88): the arguments are (x=0, xmin=1, xmax=x), i.e.
+    min(max(0, 1), x) = min(1, x) -- no lower clamp."""
+    return np.minimum(f32(1.0), x)
+
+
+def split_yuv_420(yuv):
+    """yuv_420.py:95-103."""
+    height = yuv.shape[0] * 2 // 3
+    width = yuv.shape[1]
+    return yuv[:height], yuv[height:].reshape(2, height // 2, width // 2), (width, height)
+
+
+def rgb_yuv420(src: np.ndarray, dtype: str | None = None) -> np.ndarray:
+    """rgb_yuv420_kernel + rgb_yuv420_image (yuv_420.py:39-66,105-119)."""
+    in_dt = dtype_name(src)
+    out_dt = in_dt if dtype is None else dtype
+    H, W, _ = src.shape
+    x = src.astype(f32) / f32(SCALE[in_dt])                    # :52  src / in_scale
+    y0, u0, v0 = _matvec3(YCRCB_T_BGR, x[..., 2], x[..., 1], x[..., 0])   # rgb.bgr
+    u0 = u0 + f32(0.5); v0 = v0 + f32(0.5)                      # :23  + vec3(0, 0.5, 0.5) (y + 0 is exact)
+    yuv = np.zeros((H * 3 // 2, W), dtype=NP_DTYPE[out_dt])
+    yp, uvp, _ = split_yuv_420(yuv)
+    He, We = H // 2 * 2, W // 2 * 2                             # the loop covers whole 2x2 blocks (:48)
+    yp[:He, :We] = cast_out(_clamp_quirk(y0[:He, :We]) * f32(SCALE[out_dt]), out_dt)     # :54
+    acc_u = np.zeros((He // 2, We // 2), dtype=f32); acc_v = np.zeros_like(acc_u)
+    for dr, dc in ((0, 0), (0, 1), (1, 0), (1, 1)):            # ti.ndrange(2, 2) order, sequential f32 adds (:55)
+        acc_u = acc_u + u0[dr:He:2, dc:We:2]
+        acc_v = acc_v + v0[dr:He:2, dc:We:2]
+    uvp[1] = cast_out(_clamp_quirk(acc_u / f32(4.0)) * f32(SCALE[out_dt]), out_dt)         # :57-58
+    uvp[0] = cast_out(_clamp_quirk(acc_v / f32(4.0)) * f32(SCALE[out_dt]), out_dt)         # :59
+    return yuv
+
+
+def yuv420_rgb(yuv: np.ndarray, dtype: str | None = None) -> np.ndarray:
+    """yuv420_rgb_kernel + yuv420_rgb_image (yuv_420.py:68-92,121-131)."""
+    in_dt = dtype_name(yuv)
+    out_dt = in_dt if dtype is None else dtype
+    yp, uvp, (W, H) = split_yuv_420(yuv)
+    inv = f32(SCALE[in_dt])
+    rr, cc = np.arange(H)[:, None] // 2, np.arange(W)[None, :] // 2
+    y = yp.astype(f32) / inv
+    u = uvp[1][rr, cc].astype(f32) / inv - f32(0.5)             # :84-88  (yuv / in_scale) - (0, .5, .5)
+    v = uvp[0][rr, cc].astype(f32) / inv - f32(0.5)
+    b, g, r = _matvec3(BGR_T_YCRCB, y, u, v)                    # YCrCb_bgr, then .bgr (:30-35)
+    rgb = np.stack([r, g, b], axis=-1)
+    return cast_out(_clamp_quirk(rgb) * f32(SCALE[out_dt]), out_dt)

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
-template <int MODE, int DEPTH, int THREADS>
+template <int MODE, int DEPTH, int THREADS, int ALU = 0>
 __global__ __launch_bounds__(THREADS) void rd(const uint4* __restrict__ src, long n_groups, unsigned* out) {
   const long stride = (long)gridDim.x * THREADS;
   const long tid = (long)blockIdx.x * THREADS + threadIdx.x;
@@ -34,19 +34,30 @@ __global__ __launch_bounds__(THREADS) void rd(const uint4* __restrict__ src, lon
         if (gn < n_groups) load(gn, buf[d]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc += c[j].x ^ c[j].y ^ c[j].z ^ c[j].w;
+        if (ALU > 0) {                                  // ALU fast-class instructions per group, 8 independent chains
+          float f[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] = __builtin_bit_cast(float, (c[k % 3].x & 0x007FFFFFu) | 0x3F800000u) + k;
+#pragma unroll
+          for (int a = 0; a < ALU / 8; ++a)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("v_fmac_f32_e32 %0, 0x3f800347, %1" : "+v"(f[k]) : "v"(f[(k + 1) & 7]));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc += __builtin_bit_cast(unsigned, f[k]);
+        }
       }
     }
   }
   if (acc == 0x12345678u) out[0] = acc;
 }
-template <int MODE, int DEPTH, int THREADS> void run(const char* name, const uint4* src, long n_groups, unsigned* out, int blocks) {
+template <int MODE, int DEPTH, int THREADS, int ALU = 0> void run(const char* name, const uint4* src, long n_groups, unsigned* out, int blocks) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((rd<MODE, DEPTH, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, src, n_groups, out);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((rd<MODE, DEPTH, THREADS, ALU>), dim3(blocks), dim3(THREADS), 0, 0, src, n_groups, out);
   (void)hipEventRecord(e0);
-  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((rd<MODE, DEPTH, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, src, n_groups, out);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((rd<MODE, DEPTH, THREADS, ALU>), dim3(blocks), dim3(THREADS), 0, 0, src, n_groups, out);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 20;
-  printf("%-10s depth %d  %4d thr x %5d blocks: %7.2f us  %6.2f TB/s\n", name, DEPTH, THREADS, blocks, ms * 1e3, n_groups * 48.0 / (ms * 1e-3) / 1e12);
+  printf("%-10s alu %4d depth %d  %4d thr x %5d blocks: %7.2f us  %6.2f TB/s\n", name, ALU, DEPTH, THREADS, blocks, ms * 1e3, n_groups * 48.0 / (ms * 1e-3) / 1e12);
 }
 int main() {
   const long n_groups = 4096L * 3072 / 8;
@@ -54,21 +65,16 @@ int main() {
   (void)hipMalloc(&src, n_groups * 48); (void)hipMalloc(&out, 64);
   (void)hipMemset(src, 1, n_groups * 48);
   // a second large buffer touched between runs would evict the Infinity Cache; here the image (75.5 MB) stays
-  run<0, 1, 256>("strided", src, n_groups, out, 2048);
-  run<0, 1, 256>("strided", src, n_groups, out, 6144);
-  run<0, 2, 256>("strided", src, n_groups, out, 2048);
-  run<0, 1, 512>("strided", src, n_groups, out, 512);
-  run<0, 2, 512>("strided", src, n_groups, out, 512);
-  run<0, 3, 512>("strided", src, n_groups, out, 512);
-  run<0, 2, 512>("strided", src, n_groups, out, 1024);
-  run<0, 2, 1024>("strided", src, n_groups, out, 512);
-  run<1, 1, 256>("contig", src, n_groups, out, 2048);
-  run<1, 1, 256>("contig", src, n_groups, out, 6144);
-  run<1, 2, 256>("contig", src, n_groups, out, 2048);
-  run<1, 1, 512>("contig", src, n_groups, out, 512);
-  run<1, 2, 512>("contig", src, n_groups, out, 512);
-  run<1, 3, 512>("contig", src, n_groups, out, 512);
-  run<1, 2, 512>("contig", src, n_groups, out, 1024);
-  run<1, 2, 1024>("contig", src, n_groups, out, 512);
+  run<0, 1, 512, 0>("strided", src, n_groups, out, 512);
+  run<0, 1, 512, 64>("strided", src, n_groups, out, 512);
+  run<0, 1, 512, 128>("strided", src, n_groups, out, 512);
+  run<0, 1, 512, 256>("strided", src, n_groups, out, 512);
+  run<0, 1, 512, 512>("strided", src, n_groups, out, 512);
+  run<0, 1, 512, 1024>("strided", src, n_groups, out, 512);
+  run<0, 2, 512, 256>("strided", src, n_groups, out, 512);
+  run<0, 2, 512, 512>("strided", src, n_groups, out, 512);
+  run<0, 1, 256, 256>("strided", src, n_groups, out, 2048);
+  run<0, 1, 256, 512>("strided", src, n_groups, out, 2048);
+  run<0, 1, 256, 512>("strided", src, n_groups, out, 1024);
   return 0;
 }

@@ -32,6 +32,8 @@ SIGNATURES = {
     "mi_isp_load_convert": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
     "mi_isp_demosaic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P]),
     "mi_isp_mosaic": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mi_isp_rgb_to_yuv420": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mi_isp_yuv420_to_rgb": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mi_isp_resize_bilinear": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P]),
     "mi_isp_transform": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mi_isp_metering": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P]),

@@ -246,6 +246,75 @@ __global__ __launch_bounds__(EW_THREADS) void transform_kernel(const T* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// color/yuv_420.py: RGB <-> planar YUV 4:2:0 (the step after the path).  One thread per
+// 2x2 block.  The reference's quirks are reproduced: the BGR-named matrix is applied to rgb.bgr
+// (Y = 0.299 B + 0.587 G + 0.114 R, yuv_420.py:12-27) and tm.clamp(0, 1, x) is min(1, x) (:54-57,88).
+// Layout (yuv_420.py:95-103): yuv is (H * 3 / 2, W); rows [0, H) = Y, the rest = two (H/2, W/2) planes,
+// plane 0 = yuv.z, plane 1 = yuv.y (:58-59).
+// ---------------------------------------------------------------------------------------------
+MI_DEV void ycrcb_from_rgb(float r, float g, float b, float (&yuv)[3]) {
+  // YCrCb_T_bgr @ (b, g, r) + (0, 0.5, 0.5), rows as (m0 * v0 + m1 * v1) + m2 * v2 in fp32
+  yuv[0] = (0.299f * b + 0.587f * g) + 0.114f * r;
+  yuv[1] = ((-0.168736f * b + -0.331264f * g) + 0.5f * r) + 0.5f;
+  yuv[2] = ((0.5f * b + -0.418688f * g) + -0.081312f * r) + 0.5f;
+}
+
+template <class TI, class TO>
+__global__ __launch_bounds__(EW_THREADS) void rgb_yuv420_kernel(const TI* __restrict__ src, TO* __restrict__ yuv,
+                                                                int H, int W) {
+  const int hb = H / 2, wb = W / 2;
+  const float in_scale = ScaleOf<TI>::value, out_scale = ScaleOf<TO>::value;
+  TO* yp = yuv;
+  TO* plane0 = yuv + (size_t)H * W;
+  TO* plane1 = plane0 + (size_t)hb * wb;
+  const int64_t n = (int64_t)hb * wb, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int br = (int)(i / wb), bc = (int)(i - (int64_t)br * wb);
+    float su = 0.f, sv = 0.f;
+#pragma unroll
+    for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+      for (int dc = 0; dc < 2; ++dc) {                 // ti.ndrange(2, 2) order (yuv_420.py:52)
+        const size_t px = (size_t)(2 * br + dr) * W + (2 * bc + dc);
+        const TI* p = src + px * 3;
+        float t[3];
+        ycrcb_from_rgb((float)p[0] / in_scale, (float)p[1] / in_scale, (float)p[2] / in_scale, t);
+        yp[px] = cast_out<TO>(fminf(1.0f, t[0]) * out_scale);
+        su = su + t[1]; sv = sv + t[2];
+      }
+    plane1[i] = cast_out<TO>(fminf(1.0f, su / 4.0f) * out_scale);
+    plane0[i] = cast_out<TO>(fminf(1.0f, sv / 4.0f) * out_scale);
+  }
+}
+
+template <class TI, class TO>
+__global__ __launch_bounds__(EW_THREADS) void yuv420_rgb_kernel(const TI* __restrict__ yuv, TO* __restrict__ rgb,
+                                                                int H, int W) {
+  const int hb = H / 2, wb = W / 2;
+  const float in_scale = ScaleOf<TI>::value, out_scale = ScaleOf<TO>::value;
+  const TI* yp = yuv;
+  const TI* plane0 = yuv + (size_t)H * W;
+  const TI* plane1 = plane0 + (size_t)hb * wb;
+  // bgr_T_YCrCb = inverse(YCrCb_T_bgr) evaluated in float64 (yuv_420.py:18), rounded to fp32
+  const float m[9] = {1.0f, -1.2188942e-06f, 1.4019996f, 1.0f, -0.34413567f, -0.71413618f,
+                      1.0f, 1.7720001f, 4.0629806e-07f};
+  const int64_t n = (int64_t)H * W, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i / W), c = (int)(i - (int64_t)r * W);
+    const size_t ib = (size_t)(r / 2) * wb + (c / 2);
+    const float y = (float)yp[i] / in_scale;
+    const float u = (float)plane1[ib] / in_scale - 0.5f, v = (float)plane0[ib] / in_scale - 0.5f;
+    float bgr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bgr[k] = (m[3 * k] * y + m[3 * k + 1] * u) + m[3 * k + 2] * v;
+    TO* q = rgb + (size_t)i * 3;
+    q[0] = cast_out<TO>(fminf(1.0f, bgr[2]) * out_scale);
+    q[1] = cast_out<TO>(fminf(1.0f, bgr[1]) * out_scale);
+    q[2] = cast_out<TO>(fminf(1.0f, bgr[0]) * out_scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 8-pixel (24-element) vector IO on (H, W, 3) images
 // ---------------------------------------------------------------------------------------------
 // The 24 elements of an aligned whole group as raw 16-byte (8-byte for u8) units: issued early and
@@ -970,6 +1039,44 @@ extern "C" int mi_isp_mosaic(const void* rgb, void* cfa, int H, int W, int dtype
     using T = decltype(tag);
     hipLaunchKernelGGL((mosaic_kernel<T>), dim3(grid_for((int64_t)H * W)), dim3(EW_THREADS), 0, s,
                        static_cast<const T*>(rgb), static_cast<T*>(cfa), H, W, order4);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+template <class F> static int dispatch_dtype2(int in_dtype, int out_dtype, F&& f) {
+  return dispatch_dtype(in_dtype, [&](auto ti_tag) {
+    return dispatch_dtype(out_dtype, [&](auto to_tag) { return f(ti_tag, to_tag); });
+  });
+}
+
+extern "C" int mi_isp_rgb_to_yuv420(const void* rgb, void* yuv, int H, int W, int in_dtype, int out_dtype,
+                                    void* stream) {
+  MI_REQUIRE(rgb && yuv, "rgb_to_yuv420: null pointer");
+  MI_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "rgb_to_yuv420: image must be even size, got %dx%d", H, W);
+  MI_REQUIRE(mi_valid_dtype(in_dtype) && mi_valid_dtype(out_dtype), "rgb_to_yuv420: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_dtype2(in_dtype, out_dtype, [&](auto ti_tag, auto to_tag) {
+    using TI = decltype(ti_tag);
+    using TO = decltype(to_tag);
+    hipLaunchKernelGGL((rgb_yuv420_kernel<TI, TO>), dim3(grid_for((int64_t)(H / 2) * (W / 2))), dim3(EW_THREADS), 0, s,
+                       static_cast<const TI*>(rgb), static_cast<TO*>(yuv), H, W);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
+extern "C" int mi_isp_yuv420_to_rgb(const void* yuv, void* rgb, int H, int W, int in_dtype, int out_dtype,
+                                    void* stream) {
+  MI_REQUIRE(rgb && yuv, "yuv420_to_rgb: null pointer");
+  MI_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "yuv420_to_rgb: image must be even size, got %dx%d", H, W);
+  MI_REQUIRE(mi_valid_dtype(in_dtype) && mi_valid_dtype(out_dtype), "yuv420_to_rgb: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch_dtype2(in_dtype, out_dtype, [&](auto ti_tag, auto to_tag) {
+    using TI = decltype(ti_tag);
+    using TO = decltype(to_tag);
+    hipLaunchKernelGGL((yuv420_rgb_kernel<TI, TO>), dim3(grid_for((int64_t)H * W)), dim3(EW_THREADS), 0, s,
+                       static_cast<const TI*>(yuv), static_cast<TO*>(rgb), H, W);
     MI_LAUNCH_CHECK();
     return 0;
   });

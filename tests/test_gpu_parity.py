@@ -444,3 +444,105 @@ def test_isp_constructor_and_set(ti, dev):
     with pytest.raises(TypeError):
         isp.tonemap_reinhard([], gamma=1)
     assert ti.Camera16.__qualname__ == "Camera16" and callable(ti.Camera16.reinhard_kernel)
+
+
+# ---- color/yuv_420.py (the step after the path) --------------------------------------------------
+@pytest.mark.parametrize("in_dt,out_dt", [("u8", None), ("f16", "u8"), ("f32", "f16"), ("u16", "u8"), ("f32", None)])
+@pytest.mark.parametrize("shape", [(2, 2), (6, 10), (64, 96)])
+def test_rgb_yuv420_matches_oracle(rng, dev, in_dt, out_dt, shape):
+    from taichi_image_amd import color
+    h, w = shape
+    if in_dt in ("u8", "u16"):
+        img = rng.integers(0, int(O.SCALE[in_dt]) + 1, (h, w, 3)).astype(O.NP_DTYPE[in_dt])
+    else:
+        # some values outside [0, 1]; a negative float -> unsigned cast is undefined in the reference,
+        # oracle and library both saturate it to 0
+        img = (rng.random((h, w, 3)) * 1.2 - 0.05).astype(O.NP_DTYPE[in_dt])
+    want = O.rgb_yuv420(img, out_dt)
+    got = color.rgb_yuv420_image(img, dtype=out_dt)
+    assert isinstance(got, np.ndarray)
+    assert_close(got, want, f"rgb_yuv420 {in_dt}->{out_dt} {shape}")
+    t = torch.from_numpy(img).to(dev)
+    got_t = color.rgb_yuv420_image(t, dtype=out_dt)
+    assert got_t.device == t.device
+    assert_exact(got_t.cpu().numpy(), got, "torch container gives the same result")
+
+
+@pytest.mark.parametrize("in_dt,out_dt", [("u8", None), ("u8", "f32"), ("f16", None), ("f32", "u8")])
+def test_yuv420_rgb_matches_oracle(rng, dev, in_dt, out_dt):
+    from taichi_image_amd import color
+    h, w = 12, 16
+    rgb = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    yuv8 = O.rgb_yuv420(rgb)
+    yuv = yuv8 if in_dt == "u8" else (yuv8.astype(np.float32) / 255).astype(O.NP_DTYPE[in_dt])
+    want = O.yuv420_rgb(yuv, out_dt)
+    got = color.yuv420_rgb_image(yuv, dtype=out_dt)
+    assert_close(got, want, f"yuv420_rgb {in_dt}->{out_dt}")
+    y, uv, (ww, hh) = color.split_yuv_420(got if got.ndim == 2 else yuv)
+    assert (ww, hh) == (w, h) and uv.shape == (2, h // 2, w // 2)
+
+
+def test_yuv420_4k_tonemap_output_round_trip(dev):
+    """Full-size property: u8 frame -> yuv420 -> rgb stays within the chroma-subsampling error of a
+    smooth scene, and the Y plane equals the per-pixel luma of the oracle on a crop."""
+    from taichi_image_amd import color, synthetic
+    scene = (np.clip(synthetic.synthetic_scene(3), 0, 1) * 255).astype(np.uint8)
+    t = torch.from_numpy(scene).to(dev)
+    yuv = color.rgb_yuv420_image(t)
+    assert yuv.shape == (scene.shape[0] * 3 // 2, scene.shape[1]) and yuv.dtype == torch.uint8
+    crop = scene[:64, :128]
+    assert_close(yuv[:64, :128].cpu().numpy(), O.rgb_yuv420(crop)[:64], "luma plane crop")
+    back = color.yuv420_rgb_image(yuv).cpu().numpy().astype(np.int32)
+    assert np.abs(back - scene.astype(np.int32)).mean() < 8.0
+
+
+def test_yuv420_asserts():
+    from taichi_image_amd import color
+    with pytest.raises(AssertionError):
+        color.rgb_yuv420_image(np.zeros((3, 4, 3), np.uint8))
+    with pytest.raises(AssertionError):
+        color.rgb_yuv420_image(np.zeros((4, 4), np.uint8))
+
+
+# ---- ingest path (scripts/tonemap_scan.py:64-87) --------------------------------------------------
+def test_upload_ring_pipeline_matches_direct(dev):
+    """Frames uploaded through the pinned ring while earlier frames are still being processed give
+    the results of frames that were resident from the start."""
+    from taichi_image_amd import ingest, synthetic
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    H, W = 64, 256
+    frames = [synthetic.synthetic_packed12(k, H, W) for k in range(5)]
+    ring = ingest.UploadRing(2, H * W * 3 // 2, dev)
+    outs = []
+    for f in frames:                                   # more frames than slots: slots are reused
+        slot, dev_bytes = ring.upload(f)
+        outs.append(pipeline12_reinhard(dev_bytes.view(H, W * 3 // 2)))
+        slot.release()
+    torch.cuda.synchronize()
+    for f, o in zip(frames, outs):
+        want = pipeline12_reinhard(torch.from_numpy(f).to(dev))
+        assert_exact(o.cpu().numpy(), want.cpu().numpy(), "ring-fed frame")
+
+
+def test_load_raw_bytes_and_iter(dev, tmp_path):
+    from pathlib import Path
+    from taichi_image_amd import ingest
+    rng = np.random.default_rng(5)
+    folders = [tmp_path / "cam0", tmp_path / "cam1"]
+    names = ["a.raw", "b.raw", "c.raw"]
+    blobs = {}
+    for fo in folders:
+        fo.mkdir()
+        for n in names:
+            blobs[(fo, n)] = rng.integers(0, 256, 6144, dtype=np.uint8)
+            (fo / n).write_bytes(blobs[(fo, n)].tobytes())
+    t = ingest.load_raw_bytes(folders[0] / "a.raw", device=dev)
+    assert t.device == dev and t.dtype == torch.uint8
+    assert_exact(t.cpu().numpy(), blobs[(folders[0], "a.raw")], "raw bytes")
+    from functools import partial
+    seen = []
+    for name, group in ingest.load_images_iter(partial(ingest.load_raw_bytes, device=dev), folders, names):
+        seen.append(name)
+        for fo in folders:
+            assert_exact(group[fo].cpu().numpy(), blobs[(fo, name)], f"{fo.name}/{name}")
+    assert seen == names

@@ -163,3 +163,29 @@ def test_golden_vectors_frozen():
     assert sorted(gold.files) == sorted(now)
     for k in gold.files:
         assert_exact(now[k], gold[k], k)
+
+
+# ---- color/yuv_420.py --------------------------------------------------------------------------
+def test_yuv420_known_answers():
+    """Hand-derived from yuv_420.py:12-27,52-59: the BGR-named matrix sees rgb.bgr, planes are
+    (V, U) in that order, float -> u8 truncates."""
+    white = np.full((2, 2, 3), 255, np.uint8)
+    yuv = O.rgb_yuv420(white)
+    assert yuv.shape == (3, 2) and yuv.tolist() == [[255, 255], [255, 255], [127, 127]]
+    red = np.zeros((2, 2, 3), np.uint8); red[..., 0] = 255
+    # (b, g, r) = (0, 0, 1): Y = 0.114, yuv.y = 0.5 + 0.5 = 1.0 (plane 1), yuv.z = 0.5 - 0.081312 (plane 0)
+    assert O.rgb_yuv420(red).tolist() == [[29, 29], [29, 29], [106, 255]]
+    y, uv, (w, h) = O.split_yuv_420(np.zeros((12, 8), np.uint8))
+    assert y.shape == (8, 8) and uv.shape == (2, 4, 4) and (w, h) == (8, 8)
+
+
+def test_yuv420_flat_round_trip_and_clamp_quirk(rng):
+    flat = np.empty((4, 6, 3), np.float32)
+    flat[...] = [0.2, 0.5, 0.7]
+    back = O.yuv420_rgb(O.rgb_yuv420(flat))
+    assert np.abs(back - flat).max() < 1e-5            # lossless on a constant image (fp32)
+    # tm.clamp(0, 1, x) == min(1, x): values above 1 saturate, negative ones pass through
+    hot = np.full((2, 2, 3), 1.5, np.float32)
+    assert O.rgb_yuv420(hot)[:2].max() == 1.0
+    yuv = np.zeros((3, 2), np.float32); yuv[2] = [0.0, 0.0]     # y = 0, u = v = -0.5 after the offset
+    assert O.yuv420_rgb(yuv).min() < 0.0
