@@ -278,7 +278,7 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_yuv420_kernel(const TI* __rest
         const size_t px = (size_t)(2 * br + dr) * W + (2 * bc + dc);
         const TI* p = src + px * 3;
         float t[3];
-        ycrcb_from_rgb((float)p[0] / in_scale, (float)p[1] / in_scale, (float)p[2] / in_scale, t);
+        ycrcb_from_rgb(div_scale<TI>((float)p[0]), div_scale<TI>((float)p[1]), div_scale<TI>((float)p[2]), t);
         yp[px] = cast_out<TO>(fminf(1.0f, t[0]) * out_scale);
         su = su + t[1]; sv = sv + t[2];
       }
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(EW_THREADS) void yuv420_rgb_kernel(const TI* __rest
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int r = (int)(i / W), c = (int)(i - (int64_t)r * W);
     const size_t ib = (size_t)(r / 2) * wb + (c / 2);
-    const float y = (float)yp[i] / in_scale;
-    const float u = (float)plane1[ib] / in_scale - 0.5f, v = (float)plane0[ib] / in_scale - 0.5f;
+    const float y = div_scale<TI>((float)yp[i]);
+    const float u = div_scale<TI>((float)plane1[ib]) - 0.5f, v = div_scale<TI>((float)plane0[ib]) - 0.5f;
     float bgr[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) bgr[k] = (m[3 * k] * y + m[3 * k + 1] * u) + m[3 * k + 2] * v;
@@ -382,6 +382,63 @@ template <class T> MI_DEV void store24(T* p, const float (&v)[24], int npx, bool
 #pragma unroll
     for (int i = 0; i < 24; ++i)
       if (i < npx * 3) p[i] = o[i];
+  }
+}
+
+// rgb -> yuv420, aligned images (W % 8 == 0, 16-byte aligned rows): one lane = 2 rows x 8 pixels =
+// two 24-element vector loads, two 8-element Y stores, 4 + 4 chroma stores.
+template <class T, int N> MI_DEV void store_vec(T* p, const T (&v)[N]) {
+  constexpr int BYTES = (int)sizeof(T) * N;
+  if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+    for (int i = 0; i < BYTES / 16; ++i) reinterpret_cast<uint4*>(p)[i] = reinterpret_cast<const uint4*>(v)[i];
+  } else if constexpr (BYTES % 8 == 0) {
+#pragma unroll
+    for (int i = 0; i < BYTES / 8; ++i) reinterpret_cast<uint2*>(p)[i] = reinterpret_cast<const uint2*>(v)[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < BYTES / 4; ++i) reinterpret_cast<uint32_t*>(p)[i] = reinterpret_cast<const uint32_t*>(v)[i];
+  }
+}
+
+template <class TI, class TO>
+__global__ __launch_bounds__(EW_THREADS) void rgb_yuv420_vec_kernel(const TI* __restrict__ src, TO* __restrict__ yuv,
+                                                                    int H, int W) {
+  const int hb = H / 2, wb = W / 2, groups = W / 8;
+  const float in_scale = ScaleOf<TI>::value, out_scale = ScaleOf<TO>::value;
+  TO* yp = yuv;
+  TO* plane0 = yuv + (size_t)H * W;
+  TO* plane1 = plane0 + (size_t)hb * wb;
+  const int64_t n = (int64_t)hb * groups, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int br = (int)(i / groups), g = (int)(i - (int64_t)br * groups);
+    float a[2][24];
+    load24<TI>(src + ((size_t)(2 * br) * W + 8 * g) * 3, a[0], 8, true);
+    load24<TI>(src + ((size_t)(2 * br + 1) * W + 8 * g) * 3, a[1], 8, true);
+    float u[2][8], v[2][8];
+    TO yo[2][8];
+#pragma unroll
+    for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t[3];
+        ycrcb_from_rgb(div_scale<TI>(a[dr][3 * k]), div_scale<TI>(a[dr][3 * k + 1]), div_scale<TI>(a[dr][3 * k + 2]), t);
+        yo[dr][k] = cast_out<TO>(fminf(1.0f, t[0]) * out_scale);
+        u[dr][k] = t[1]; v[dr][k] = t[2];
+      }
+    TO uo[4], vo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // the reference's order: (0,0), (0,1), (1,0), (1,1), starting from 0 (yuv_420.py:50-55)
+      const float su = (((0.f + u[0][2 * c]) + u[0][2 * c + 1]) + u[1][2 * c]) + u[1][2 * c + 1];
+      const float sv = (((0.f + v[0][2 * c]) + v[0][2 * c + 1]) + v[1][2 * c]) + v[1][2 * c + 1];
+      uo[c] = cast_out<TO>(fminf(1.0f, su / 4.0f) * out_scale);
+      vo[c] = cast_out<TO>(fminf(1.0f, sv / 4.0f) * out_scale);
+    }
+    store_vec<TO, 8>(yp + (size_t)(2 * br) * W + 8 * g, yo[0]);
+    store_vec<TO, 8>(yp + (size_t)(2 * br + 1) * W + 8 * g, yo[1]);
+    store_vec<TO, 4>(plane1 + (size_t)br * wb + 4 * g, uo);
+    store_vec<TO, 4>(plane0 + (size_t)br * wb + 4 * g, vo);
   }
 }
 
@@ -1059,8 +1116,15 @@ extern "C" int mi_isp_rgb_to_yuv420(const void* rgb, void* yuv, int H, int W, in
   return dispatch_dtype2(in_dtype, out_dtype, [&](auto ti_tag, auto to_tag) {
     using TI = decltype(ti_tag);
     using TO = decltype(to_tag);
-    hipLaunchKernelGGL((rgb_yuv420_kernel<TI, TO>), dim3(grid_for((int64_t)(H / 2) * (W / 2))), dim3(EW_THREADS), 0, s,
-                       static_cast<const TI*>(rgb), static_cast<TO*>(yuv), H, W);
+    // vector path: whole 8-pixel groups, and every row of every plane 16-byte aligned
+    const bool vec = W % 16 == 0 && ((uintptr_t)rgb & 15) == 0 && ((uintptr_t)yuv & 15) == 0 &&
+                     ((size_t)(H / 2) * (W / 2) * sizeof(TO)) % 16 == 0;
+    if (vec)
+      hipLaunchKernelGGL((rgb_yuv420_vec_kernel<TI, TO>), dim3(grid_for((int64_t)(H / 2) * (W / 8))), dim3(EW_THREADS), 0,
+                         s, static_cast<const TI*>(rgb), static_cast<TO*>(yuv), H, W);
+    else
+      hipLaunchKernelGGL((rgb_yuv420_kernel<TI, TO>), dim3(grid_for((int64_t)(H / 2) * (W / 2))), dim3(EW_THREADS), 0, s,
+                         static_cast<const TI*>(rgb), static_cast<TO*>(yuv), H, W);
     MI_LAUNCH_CHECK();
     return 0;
   });

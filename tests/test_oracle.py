@@ -189,3 +189,17 @@ def test_yuv420_flat_round_trip_and_clamp_quirk(rng):
     assert O.rgb_yuv420(hot)[:2].max() == 1.0
     yuv = np.zeros((3, 2), np.float32); yuv[2] = [0.0, 0.0]     # y = 0, u = v = -0.5 after the offset
     assert O.yuv420_rgb(yuv).min() < 0.0
+
+
+def test_scaled_division_trick():
+    """csrc/isp_common.h div_scale: x * RN(1/d) with one FMA residual correction equals the IEEE
+    division x / d for every integer x in [0, d], d = 255 and 65535 (the plain product does not)."""
+    f32 = np.float32
+    for d in (255.0, 65535.0):
+        x = np.arange(0, int(d) + 1, dtype=np.float64)
+        r = f32(1.0) / f32(d)
+        q = (x.astype(f32) * r).astype(f32)
+        e = (x - q.astype(np.float64) * d).astype(f32)                  # fma(-q, d, x): exact product, one rounding
+        q2 = (q.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(f32)
+        want = x.astype(f32) / f32(d)
+        assert (q != want).any() and np.array_equal(q2, want)
