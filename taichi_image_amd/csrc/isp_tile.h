@@ -281,6 +281,44 @@ MI_DEV void fill_packed_fast(const Params& p, float* lds, int rb, int cb) {
   }
 }
 
+// Plain f16 / f32 CFA with aligned rows and whole tiles (HOT == 2): the same 8-pixel units as the
+// packed fast path, 16 / 32 bytes per lane and unit, every load issued before the first use.
+template <class S>
+MI_DEV void fill_cfa_fast(const Params& p, float* lds, int rb, int cb) {
+  constexpr int NUNITS = LDS_ROWS * UNITS;
+  constexpr int NIT = (NUNITS + THREADS - 1) / THREADS;
+  constexpr int NQ = (int)sizeof(S) * 8 / 16;          // uint4 loads per unit
+  const S* base = static_cast<const S*>(p.src);
+  uint4 raw[NIT][NQ];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int u = threadIdx.x + it * THREADS;
+    const int lr = (u * 3641) >> 16;                 // u / 18 for u < 16384
+    const int lu = u - lr * UNITS;
+    const int r = rb + lr, c = cb + lu * 8;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) raw[it][q] = make_uint4(0, 0, 0, 0);     // zero bits are 0.0 in f16 and f32
+    if (u < NUNITS && r >= 0 && r < p.H && c >= 0 && c < p.W) {
+      const uint4* src4 = reinterpret_cast<const uint4*>(base + (size_t)r * p.W + c);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) raw[it][q] = src4[q];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int u = threadIdx.x + it * THREADS;
+    if (u >= NUNITS) continue;
+    const int lr = (u * 3641) >> 16;
+    const int lu = u - lr * UNITS;
+    S t[8];
+    __builtin_memcpy(t, raw[it], sizeof(t));
+    float out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)t[i];
+    lds_store8(lds + lr * PITCH + lu * 4, 0, out);
+  }
+}
+
 // Plain CFA images (u8 / u16 / f16 / f32): coalesced scalar loads, exact widening to fp32.
 template <class S>
 MI_DEV void fill_plain(const Params& p, float* lds, int rb, int cb) {
@@ -461,13 +499,13 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 // ---------------------------------------------------------------------------------------------
 // HOT: the configuration of the packed-RAW pipelines, fixed at compile time so that the kernel is
 // straight-line code without the generic paths: standard 12-bit packing with aligned rows, whole
-// tiles only (W % 128 == 0, H % 32 == 0), no colour matrix, stores in the work dtype (see hot_ok).
+// tiles only (W % 128 == 0, H % 32 == 0), no colour matrix, stores in the work dtype (see hot_spec); HOT == 2: the same for a plain f16 / f32 CFA image.
 // measurement aid (make EXTRA=-DMI_TILE_STAMPS): wave 0 of every block leaves s_memtime stamps of its
 // phases in workspace rows 2.. (32-bit, 8 per block); see scripts/tile_stamps.py
 #ifdef MI_TILE_STAMPS
 #define MI_STAMP(i)                                                                                      \
   do {                                                                                                   \
-    if (HOT && threadIdx.x == 0)                                                                         \
+    if (HOT != 0 && threadIdx.x == 0)                                                                      \
       reinterpret_cast<unsigned*>(p.partials + 2 * (size_t)p.part_stride)[blockIdx.x * 8 + (i)] =       \
           (unsigned)__builtin_readcyclecounter();                                                        \
   } while (0)
@@ -475,12 +513,13 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 #define MI_STAMP(i) do {} while (0)
 #endif
 template <class E> constexpr int dtype_code() { return sizeof(E) == 2 ? (int)MI_F16 : (int)MI_F32; }
-template <class E, int PR, int PC, int EPI, bool HOT = false>
+template <class E, int PR, int PC, int EPI, int HOT = 0>
 __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   constexpr bool EXACT = sizeof(E) == 2;
   Params p = p_in;
-  if constexpr (HOT) {
-    p.src_kind = SRC_PACKED12; p.src_fast = 1; p.has_ccm = 0; p.in_scale = 1.f; p.debug_skip = 0;
+  if constexpr (HOT != 0) {
+    p.src_kind = HOT == 1 ? (int)SRC_PACKED12 : dtype_code<E>();       // SRC_CFA_* share the MI_* numbering
+    p.src_fast = 1; p.has_ccm = 0; p.in_scale = 1.f; p.debug_skip = 0;
     p.vec_store = 1; p.out_dtype = dtype_code<E>(); p.out_scale = 1.f;
   }
   __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * PITCH];
@@ -501,7 +540,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   const int r0 = by * TILE_H, c0 = bx * TILE_W;
 
   MI_STAMP(0);
-  if constexpr (HOT) fill_packed_fast<E>(p, lds, r0 - 2, c0 - 8);
+  if constexpr (HOT == 1) fill_packed_fast<E>(p, lds, r0 - 2, c0 - 8);
+  else if constexpr (HOT == 2) fill_cfa_fast<E>(p, lds, r0 - 2, c0 - 8);
   else if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
   MI_STAMP(1);
   __syncthreads();
@@ -509,8 +549,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
 
   const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
   const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
-  const bool active = HOT || (r < p.H && c < p.W && !(p.debug_skip & 2));   // H, W even -> both rows, pixel pairs in
-  const int npx = HOT ? 8 : (active ? (p.W - c < 8 ? p.W - c : 8) : 0);
+  const bool active = HOT != 0 || (r < p.H && c < p.W && !(p.debug_skip & 2));   // H, W even -> both rows, pixel pairs in
+  const int npx = HOT != 0 ? 8 : (active ? (p.W - c < 8 ? p.W - c : 8) : 0);
 
   // tonemap scalars (uniform loads); unused ones are dead code per EPI
   float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f;
@@ -531,7 +571,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   if (active) load_window(lds, tx, ty, win);
   // a full tile with 1/2-byte outputs is stored wave-cooperatively through the (now free) tile buffer
   const bool coop_store = STORES && p.out_dtype != MI_F32 &&
-                          (HOT || (p.vec_store && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W && !(p.debug_skip & 32)));
+                          (HOT != 0 || (p.vec_store && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W && !(p.debug_skip & 32)));
   if (STORES) __syncthreads();                          // every wave holds its window
   MI_STAMP(3);
   void* stage = lds + (threadIdx.x >> 6) * (64 * 12);   // 3 KB per wave
@@ -541,7 +581,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
     // Wave-uniform predicates (scalar branches): the slow blocks below are real branches that
     // interior waves skip, not per-lane selects the compiler would flatten into the fast stream.
     const bool wave_has_slow = __builtin_amdgcn_ballot_w64(!fast) != 0 && !(p.debug_skip & 16);
-    const bool wave_all_full = HOT || __builtin_amdgcn_ballot_w64(npx != 8) == 0;
+    const bool wave_all_full = HOT != 0 || __builtin_amdgcn_ballot_w64(npx != 8) == 0;
 
     static_for<0, 2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -717,11 +757,19 @@ static inline int launch(const Params& p, int work_dtype, int pattern, int epi, 
   }
 }
 
-// may this launch use the HOT specialisation of epilogue `epi`?
-static inline bool hot_ok(const Params& p, int work_dtype, int epi) {
+// which compile-time specialisation (template parameter HOT) may this launch of epilogue `epi` use?
+// 0: none; 1: packed 12-bit source (standard layout, aligned rows); 2: plain f16 / f32 CFA of the work
+// dtype with 16-byte aligned rows.  Both: whole tiles, no colour matrix, stores in the work dtype.
+static inline int hot_spec(const Params& p, int work_dtype, int epi) {
   const bool stores = epi == EPI_STORE || epi == EPI_STORE_MINMAX;
-  return stores && p.src_kind == SRC_PACKED12 && p.src_fast && !p.has_ccm && p.in_scale == 1.f && p.debug_skip == 0 &&
-         p.W % TILE_W == 0 && p.H % TILE_H == 0 && p.vec_store && p.out_dtype == work_dtype && p.out_scale == 1.f;
+  const bool common = stores && !p.has_ccm && p.in_scale == 1.f && p.debug_skip == 0 && p.W % TILE_W == 0 &&
+                      p.H % TILE_H == 0 && p.vec_store && p.out_dtype == work_dtype && p.out_scale == 1.f;
+  if (!common) return 0;
+  if (p.src_kind == SRC_PACKED12 && p.src_fast) return 1;
+  if (epi == EPI_STORE && p.src_kind == work_dtype && (work_dtype == MI_F16 || work_dtype == MI_F32) &&
+      ((uintptr_t)p.src & 15) == 0)
+    return 2;
+  return 0;
 }
 
 static inline int num_tiles(int H, int W) {
