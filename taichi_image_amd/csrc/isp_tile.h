@@ -281,15 +281,16 @@ MI_DEV void fill_packed_fast(const Params& p, float* lds, int rb, int cb) {
   }
 }
 
-// Plain f16 / f32 CFA with aligned rows and whole tiles (HOT == 2): the same 8-pixel units as the
-// packed fast path, 16 / 32 bytes per lane and unit, every load issued before the first use.
+// Plain CFA with aligned rows and whole tiles (HOT == 2, 3): the same 8-pixel units as the packed
+// fast path, 8 / 16 / 32 bytes per lane and unit, every load issued before the first use.
 template <class S>
 MI_DEV void fill_cfa_fast(const Params& p, float* lds, int rb, int cb) {
   constexpr int NUNITS = LDS_ROWS * UNITS;
   constexpr int NIT = (NUNITS + THREADS - 1) / THREADS;
-  constexpr int NQ = (int)sizeof(S) * 8 / 16;          // uint4 loads per unit
+  typedef typename std::conditional<sizeof(S) == 1, uint2, uint4>::type Q;   // 8 pixels = 8 / 16 / 32 bytes
+  constexpr int NQ = (int)(sizeof(S) * 8 / sizeof(Q));
   const S* base = static_cast<const S*>(p.src);
-  uint4 raw[NIT][NQ];
+  Q raw[NIT][NQ];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int u = threadIdx.x + it * THREADS;
@@ -297,9 +298,9 @@ MI_DEV void fill_cfa_fast(const Params& p, float* lds, int rb, int cb) {
     const int lu = u - lr * UNITS;
     const int r = rb + lr, c = cb + lu * 8;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) raw[it][q] = make_uint4(0, 0, 0, 0);     // zero bits are 0.0 in f16 and f32
+    for (int q = 0; q < NQ; ++q) raw[it][q] = Q{};                        // zero bits are 0 in every CFA dtype
     if (u < NUNITS && r >= 0 && r < p.H && c >= 0 && c < p.W) {
-      const uint4* src4 = reinterpret_cast<const uint4*>(base + (size_t)r * p.W + c);
+      const Q* src4 = reinterpret_cast<const Q*>(base + (size_t)r * p.W + c);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) raw[it][q] = src4[q];
     }
@@ -499,7 +500,7 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 // ---------------------------------------------------------------------------------------------
 // HOT: the configuration of the packed-RAW pipelines, fixed at compile time so that the kernel is
 // straight-line code without the generic paths: standard 12-bit packing with aligned rows, whole
-// tiles only (W % 128 == 0, H % 32 == 0), no colour matrix, stores in the work dtype (see hot_spec); HOT == 2: the same for a plain f16 / f32 CFA image.
+// tile columns and whole waves (W % 128 == 0, H % 8 == 0), no colour matrix, stores in the work dtype (see hot_spec); HOT == 2: the same for a plain f16 / f32 CFA image.
 // measurement aid (make EXTRA=-DMI_TILE_STAMPS): wave 0 of every block leaves s_memtime stamps of its
 // phases in workspace rows 2.. (32-bit, 8 per block); see scripts/tile_stamps.py
 #ifdef MI_TILE_STAMPS
@@ -517,10 +518,14 @@ template <class E, int PR, int PC, int EPI, int HOT = 0>
 __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   constexpr bool EXACT = sizeof(E) == 2;
   Params p = p_in;
+  // HOT == 3: integer CFA, u8 for the f16 work type and u16 for f32 (mi_isp_demosaic), same dtype out
+  typedef typename std::conditional<HOT == 3, typename std::conditional<sizeof(E) == 2, uint8_t, uint16_t>::type, E>::type CfaT;
   if constexpr (HOT != 0) {
-    p.src_kind = HOT == 1 ? (int)SRC_PACKED12 : dtype_code<E>();       // SRC_CFA_* share the MI_* numbering
-    p.src_fast = 1; p.has_ccm = 0; p.in_scale = 1.f; p.debug_skip = 0;
-    p.vec_store = 1; p.out_dtype = dtype_code<E>(); p.out_scale = 1.f;
+    constexpr int cfa_code = HOT == 3 ? (sizeof(E) == 2 ? (int)MI_U8 : (int)MI_U16) : dtype_code<E>();
+    p.src_kind = HOT == 1 ? (int)SRC_PACKED12 : cfa_code;              // SRC_CFA_* share the MI_* numbering
+    p.src_fast = 1; p.has_ccm = 0; p.debug_skip = 0; p.vec_store = 1;
+    p.in_scale = HOT == 3 ? ScaleOf<CfaT>::value : 1.f;
+    p.out_dtype = cfa_code; p.out_scale = p.in_scale;
   }
   __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * PITCH];
   __shared__ float red[4][8];
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
 
   MI_STAMP(0);
   if constexpr (HOT == 1) fill_packed_fast<E>(p, lds, r0 - 2, c0 - 8);
-  else if constexpr (HOT == 2) fill_cfa_fast<E>(p, lds, r0 - 2, c0 - 8);
+  else if constexpr (HOT >= 2) fill_cfa_fast<CfaT>(p, lds, r0 - 2, c0 - 8);
   else if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
   MI_STAMP(1);
   __syncthreads();
@@ -549,7 +554,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
 
   const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
   const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
-  const bool active = HOT != 0 || (r < p.H && c < p.W && !(p.debug_skip & 2));   // H, W even -> both rows, pixel pairs in
+  // H, W even -> both rows, pixel pairs in.  HOT: whole tile columns; H % 8 == 0, so a wave (8 rows) is all in or all out
+  const bool active = HOT != 0 ? r < p.H : (r < p.H && c < p.W && !(p.debug_skip & 2));
   const int npx = HOT != 0 ? 8 : (active ? (p.W - c < 8 ? p.W - c : 8) : 0);
 
   // tonemap scalars (uniform loads); unused ones are dead code per EPI
@@ -605,25 +611,39 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
         // wave needs it, e.g. only columns 0-1 of a left-edge strip are border pixels.  All lookups
         // are issued before the first use.
         const int rmask = inside_mask(r + i, p.H);
+        // interior pixels of an integer CFA (in_scale 255 / 65535, t = 16): c / (in_scale * 16) as
+        // c * RN(1 / d) with one FMA residual correction - equal to the IEEE division for every integer c
+        // these sums can take (tests/test_oracle.py::test_scaled_division_trick), a quarter of its cost
+        const float d16 = p.in_scale * 16.f, r16 = 1.0f / d16;
         uint32_t tq[8];
         static_for<0, 8>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           constexpr int KIDX = ((i + PR) & 1) + 2 * ((k + PC) & 1);
           const int cmask = inside_mask(c + k, p.W);
-          const bool need = p.in_scale != 1.f || rmask != 31 || cmask != 31;
+          const bool border = rmask != 31 || cmask != 31;
           tq[k] = 0x101010u;                                            // t = 16 for all channels
-          if (__builtin_amdgcn_ballot_w64(need) != 0) tq[k] = BORDER_T.t[KIDX][rmask][cmask];
+          if (__builtin_amdgcn_ballot_w64(border) != 0) tq[k] = BORDER_T.t[KIDX][rmask][cmask];
         });
         static_for<0, 8>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           const int cmask = inside_mask(c + k, p.W);
           const bool need = p.in_scale != 1.f || rmask != 31 || cmask != 31;
           if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            if (__builtin_amdgcn_ballot_w64(tq[k] != 0x101010u) == 0) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-              const float t = (float)(int)(int8_t)(tq[k] >> (8 * ch));
-              const float fixed = (v[3 * k + ch] * 16.f) / (p.in_scale * t);
-              v[3 * k + ch] = need ? fixed : v[3 * k + ch];
+              for (int ch = 0; ch < 3; ++ch) {
+                const float cnum = v[3 * k + ch] * 16.f;
+                const float q = cnum * r16;
+                const float fixed = __builtin_fmaf(__builtin_fmaf(-q, d16, cnum), r16, q);
+                v[3 * k + ch] = need ? fixed : v[3 * k + ch];
+              }
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) {
+                const float t = (float)(int)(int8_t)(tq[k] >> (8 * ch));
+                const float fixed = (v[3 * k + ch] * 16.f) / (p.in_scale * t);
+                v[3 * k + ch] = need ? fixed : v[3 * k + ch];
+              }
             }
           }
         });
@@ -759,16 +779,20 @@ static inline int launch(const Params& p, int work_dtype, int pattern, int epi, 
 
 // which compile-time specialisation (template parameter HOT) may this launch of epilogue `epi` use?
 // 0: none; 1: packed 12-bit source (standard layout, aligned rows); 2: plain f16 / f32 CFA of the work
-// dtype with 16-byte aligned rows.  Both: whole tiles, no colour matrix, stores in the work dtype.
+// dtype with 16-byte aligned rows; 3: u8 / u16 CFA, same dtype out.  All: whole tiles, no colour matrix.
 static inline int hot_spec(const Params& p, int work_dtype, int epi) {
   const bool stores = epi == EPI_STORE || epi == EPI_STORE_MINMAX;
-  const bool common = stores && !p.has_ccm && p.in_scale == 1.f && p.debug_skip == 0 && p.W % TILE_W == 0 &&
-                      p.H % TILE_H == 0 && p.vec_store && p.out_dtype == work_dtype && p.out_scale == 1.f;
+  const bool common = stores && !p.has_ccm && p.debug_skip == 0 && p.W % TILE_W == 0 && p.H % 8 == 0 && p.vec_store;
   if (!common) return 0;
-  if (p.src_kind == SRC_PACKED12 && p.src_fast) return 1;
-  if (epi == EPI_STORE && p.src_kind == work_dtype && (work_dtype == MI_F16 || work_dtype == MI_F32) &&
-      ((uintptr_t)p.src & 15) == 0)
-    return 2;
+  const bool unit = p.in_scale == 1.f && p.out_scale == 1.f && p.out_dtype == work_dtype;
+  if (unit && p.src_kind == SRC_PACKED12 && p.src_fast) return 1;
+  if (epi != EPI_STORE || ((uintptr_t)p.src & 15) != 0) return 0;
+  if (unit && p.src_kind == work_dtype && (work_dtype == MI_F16 || work_dtype == MI_F32)) return 2;
+  // 3: integer CFA (u8 with the f16 work type, u16 with f32), same dtype out
+  const int int_kind = work_dtype == MI_F16 ? (int)MI_U8 : (int)MI_U16;
+  if (p.src_kind == int_kind && p.out_dtype == int_kind && p.in_scale == mi_scale_factor(int_kind) &&
+      p.out_scale == p.in_scale)
+    return 3;
   return 0;
 }
 

@@ -119,7 +119,7 @@ def test_rgb_to_bayer(ti, rng, p):
 
 @pytest.mark.parametrize("p", [0, 1, 2, 3])
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(2, 2), (4, 6), (34, 130), (66, 264), (64, 256)])
+@pytest.mark.parametrize("shape", [(2, 2), (4, 6), (34, 130), (66, 264), (64, 256), (40, 128)])
 def test_demosaic_bit_exact(ti, rng, p, dtype, shape):
     cfa = random_cfa(rng, *shape, dtype)
     got = ti.bayer.bayer_to_rgb(cfa, pat(ti, p))
@@ -264,7 +264,7 @@ def test_tonemap_reinhard_black_pixels(ti, rng):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("p,ids", [(0, False), (1, False), (2, True), (3, False)])
 @pytest.mark.parametrize("work,dout", [("f16", "f16"), ("f16", "u8"), ("f32", "f32")])
-@pytest.mark.parametrize("shape", [(64, 256), (70, 200), (34, 136)])
+@pytest.mark.parametrize("shape", [(64, 256), (70, 200), (34, 136), (40, 128)])
 def test_pipeline12_reinhard(ti, rng, dev, p, ids, work, dout, shape):
     from taichi_image_amd.pipeline import pipeline12_reinhard
     packed = natural_packed12(rng, *shape, pattern=p, ids_format=ids)
