@@ -10,7 +10,7 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
         name = row["Kernel_Name"]
         if "tile_kernel" not in name and "finalize" not in name and "rgb_pass" not in name and "metering" not in name:
             continue
-        short = name.split("tile_kernel")[-1][:28] if "tile_kernel" in name else name[:40]
+        short = name[:60]
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k)
