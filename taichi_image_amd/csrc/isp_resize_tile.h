@@ -52,7 +52,8 @@ MI_DEV int quad_origin(int i, float s, int n) {
 // One demosaiced source pixel (bayer.py:138-155) at run-time position (rr, cc): kernel KIDX,
 // taps from the LDS region whose element (0, 0) is image (rb, cb).  The weights are literals:
 // an SGPR operand would halve the issue rate of every FMA (scratch/issue_bench.hip).
-template <int KIDX, bool EXACT>
+// BORDER = false: the caller knows that no lane of the wave is near the image frame (and in_scale == 1).
+template <int KIDX, bool EXACT, bool BORDER = true>
 MI_DEV void demosaic_at(const Params& p, const float* lds, int rb, int cb, int rr, int cc, float (&rgb)[3]) {
   const float* ctr = lds + (rr - rb) * PITCH + (cc - cb);
   float acc[3];
@@ -72,8 +73,8 @@ MI_DEV void demosaic_at(const Params& p, const float* lds, int rb, int cb, int r
     });
   });
   // border pixels / CFAs with scale != 1: (acc * 16) / (in_scale * t), as in the tile kernel
-  const bool need = p.in_scale != 1.f || rr < 2 || rr >= p.H - 2 || cc < 2 || cc >= p.W - 2;
-  if (__builtin_amdgcn_ballot_w64(need) != 0) {
+  const bool need = BORDER && (p.in_scale != 1.f || rr < 2 || rr >= p.H - 2 || cc < 2 || cc >= p.W - 2);
+  if (BORDER && __builtin_amdgcn_ballot_w64(need) != 0) {
     float t3[3];
     tile::border_weight<KIDX>(rr, cc, p.H, p.W, t3);
 #pragma unroll
@@ -230,10 +231,19 @@ __global__ __launch_bounds__(THREADS) void resize_tile_kernel(const RParams rp_i
     const int par_c = (qc + PC) & 1;
     const int col0 = qc + par_c, col1 = qc + 1 - par_c;
     float P[2][2][3];                                                            // [row parity][col parity][rgb]
-    demosaic_at<0, EXACT>(p, lds, rb, cb, row0, col0, P[0][0]);
-    demosaic_at<1, EXACT>(p, lds, rb, cb, row1, col0, P[1][0]);
-    demosaic_at<2, EXACT>(p, lds, rb, cb, row0, col1, P[0][1]);
-    demosaic_at<3, EXACT>(p, lds, rb, cb, row1, col1, P[1][1]);
+    // one frame test per quad (its four sites reach rows qr-2..qr+3, columns qc-2..qc+3), one scalar branch
+    const bool near_frame = p.in_scale != 1.f || qr < 2 || qr + 1 >= p.H - 2 || qc < 2 || qc + 1 >= p.W - 2;
+    if (__builtin_amdgcn_ballot_w64(near_frame) != 0) {
+      demosaic_at<0, EXACT, true>(p, lds, rb, cb, row0, col0, P[0][0]);
+      demosaic_at<1, EXACT, true>(p, lds, rb, cb, row1, col0, P[1][0]);
+      demosaic_at<2, EXACT, true>(p, lds, rb, cb, row0, col1, P[0][1]);
+      demosaic_at<3, EXACT, true>(p, lds, rb, cb, row1, col1, P[1][1]);
+    } else {
+      demosaic_at<0, EXACT, false>(p, lds, rb, cb, row0, col0, P[0][0]);
+      demosaic_at<1, EXACT, false>(p, lds, rb, cb, row1, col0, P[1][0]);
+      demosaic_at<2, EXACT, false>(p, lds, rb, cb, row0, col1, P[0][1]);
+      demosaic_at<3, EXACT, false>(p, lds, rb, cb, row1, col1, P[1][1]);
+    }
     const bool ca1 = ((ca + PC) & 1) != 0, cb1 = ((cbm + PC) & 1) != 0;          // site parity of each column tap
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
