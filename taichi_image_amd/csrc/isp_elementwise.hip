@@ -476,7 +476,22 @@ struct PassArgs {
   const float* pull_partials; int pull_stride, pull_n, pull_bounds_post;
   float pull_npx, pull_intensity;
   float* fp_w;
+  // ISP Reinhard (batched): pass 1 derives its scalars from the metering state in its prologue instead of
+  // a 1-thread prep launch, pass 2 folds its image's partial maxima instead of a maxout launch
+  const float* isp_state9;  // PM_ISP_RH_P1: camera_isp.py:186-195 evaluated per block (NULL: read fp)
+  int pull_maxout_n;        // PM_ISP_RH_P2: partial maxima per image at partials[part_stride + y * n + i] (0: read maxouts)
 };
+
+// camera_isp.py:186-195: the Reinhard scalars of the ISP path from the metering 9-vector
+MI_DEV void isp_reinhard_scalars(const float* state9, float* fp, float intensity, float ca) {
+  const float bmin = state9[0], bmax = state9[1], lmin = state9[2], lmax = state9[3];
+  const float lmean = state9[4], mean = state9[5];
+  const float key = (lmax - lmean) / (lmax - lmin);
+  fp[FP_LO] = bmin; fp[FP_HI] = bmax; fp[FP_INV] = 1.0f / (bmax - bmin);
+  fp[FP_MAPKEY] = 0.3f + 0.7f * powf(key, 1.4f);
+  fp[FP_EI] = expf(-intensity);
+  for (int c = 0; c < 3; ++c) fp[FP_MEAN3 + c] = mean + ca * (state9[6 + c] - mean);
+}
 
 // Prologue of a pass with a pulled finalize: sh_fp = the FrameParams this block works with.
 template <int FIN>
@@ -591,7 +606,15 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   if constexpr (PULL_FIN >= 0) {
     if (pulled) pull_finalize<PULL_FIN>(a, sh_fp, sh_tot);
   }
-  auto fpv = [&](int i) { return pulled ? sh_fp[i] : a.fp[i]; };
+  bool isp_prep = false;
+  if constexpr (MODE == PM_ISP_RH_P1) {
+    isp_prep = a.isp_state9 != nullptr;
+    if (isp_prep) {
+      if (threadIdx.x == 0) isp_reinhard_scalars(a.isp_state9, sh_fp, a.pull_intensity, a.ca);
+      __syncthreads();
+    }
+  }
+  auto fpv = [&](int i) { return (pulled || isp_prep) ? sh_fp[i] : a.fp[i]; };
 
   float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f, maxout_inv = 1.f;
   ReinhardK rk;
@@ -602,7 +625,23 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
     rk.mean3[0] = fpv(FP_MEAN3); rk.mean3[1] = fpv(FP_MEAN3 + 1); rk.mean3[2] = fpv(FP_MEAN3 + 2);
   }
   if (MODE == PM_RH_STORE) { lo2 = fpv(FP_LO2); inv2 = fpv(FP_INV2); }
-  if (MODE == PM_ISP_RH_P2) maxout_inv = 1.0f / (a.batched ? a.maxouts[blockIdx.y] : a.fp[FP_MAXOUT]);
+  if constexpr (MODE == PM_ISP_RH_P2) {
+    if (a.batched && a.pull_maxout_n > 0) {
+      // max_out of this block's image (camera_isp.py:190,213): fold the partial maxima pass 1 left
+      const float* pm = a.partials + a.part_stride + (size_t)blockIdx.y * a.pull_maxout_n;
+      float m = -__builtin_inff();
+      for (int i = threadIdx.x; i < a.pull_maxout_n; i += PASS_THREADS) m = fmaxf(m, pm[i]);
+      m = wave_max(m);
+      if ((threadIdx.x & 63) == 0) sh_fp[threadIdx.x >> 6] = m;
+      __syncthreads();
+      m = sh_fp[0];
+#pragma unroll
+      for (int w = 1; w < PASS_THREADS / 64; ++w) m = fmaxf(m, sh_fp[w]);
+      maxout_inv = 1.0f / fmaxf(1e-6f, m);
+    } else {
+      maxout_inv = 1.0f / (a.batched ? a.maxouts[blockIdx.y] : a.fp[FP_MAXOUT]);
+    }
+  }
 
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
   StatsAcc st; st.init();
@@ -867,14 +906,7 @@ __global__ __launch_bounds__(EW_THREADS) void maxout_batch_kernel(const float* _
 }
 
 __global__ void isp_reinhard_prep_kernel(const float* state9, float* fp, float intensity, float ca) {
-  // camera_isp.py:186-195
-  const float bmin = state9[0], bmax = state9[1], lmin = state9[2], lmax = state9[3];
-  const float lmean = state9[4], mean = state9[5];
-  const float key = (lmax - lmean) / (lmax - lmin);
-  fp[FP_LO] = bmin; fp[FP_HI] = bmax; fp[FP_INV] = 1.0f / (bmax - bmin);
-  fp[FP_MAPKEY] = 0.3f + 0.7f * powf(key, 1.4f);
-  fp[FP_EI] = expf(-intensity);
-  for (int c = 0; c < 3; ++c) fp[FP_MEAN3 + c] = mean + ca * (state9[6 + c] - mean);
+  isp_reinhard_scalars(state9, fp, intensity, ca);
 }
 
 }  // namespace
@@ -1328,12 +1360,12 @@ extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, 
   float* partials = fp + FP_COUNT;
   const int cap = mi_partial_cap(H, W);
   if (n == 0) return 0;
-  if (int rc = isp_reinhard_prep(state9, fp, intensity, color_adapt, s)) return rc;
   for (int i0 = 0; i0 < n; i0 += 64) {
     const int m = n - i0 < 64 ? n - i0 : 64;
     PassArgs a = {};
     a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
     a.vec_in = 1; a.vec_out = 1;
+    a.isp_state9 = state9; a.pull_intensity = intensity;     // scalars derived in pass 1's prologue
     for (int i = 0; i < m; ++i) {
       MI_REQUIRE(images[i0 + i] && outs[i0 + i], "reinhard_batch: image %d is null", i0 + i);
       a.srcs.p[i] = images[i0 + i]; a.dsts.p[i] = outs[i0 + i];
@@ -1347,8 +1379,7 @@ extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, 
     float* maxouts = partials + (size_t)2 * cap;           // partial row 2: unused by the 2-row reductions
     a.maxouts = maxouts;
     if (int rc = launch_pass(PM_ISP_RH_P1, dtype, MI_U8, a, nb, s, m)) return rc;
-    hipLaunchKernelGGL(maxout_batch_kernel, dim3(m), dim3(EW_THREADS), 0, s, partials + cap, nb, maxouts);
-    MI_LAUNCH_CHECK();
+    a.pull_maxout_n = nb;                                    // max_out per image folded in pass 2's prologue
     if (int rc = launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s, m)) return rc;
   }
   return 0;
