@@ -546,3 +546,21 @@ def test_load_raw_bytes_and_iter(dev, tmp_path):
         for fo in folders:
             assert_exact(group[fo].cpu().numpy(), blobs[(fo, name)], f"{fo.name}/{name}")
     assert seen == names
+
+
+def test_isp_sharded_metering_path_equals_fused(ti, rng, dev):
+    """The multi-GPU variant of update_metering (mi_isp_metering_bounds -> exchange -> mi_isp_metering_sums
+    -> exchange, taichi_image_amd/distributed.py) on one rank equals the single-call path: same
+    statistics, same outputs over three consecutive calls (the moving average is exercised)."""
+    H, W = 96, 160
+    frames = [torch.from_numpy(natural_packed12(rng, H, W)).to(dev) for _ in range(3)]
+    a = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+    b = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev, process_group=object())   # one "rank"
+    for step in range(3):
+        fa = [a.load_packed12(f) for f in frames]
+        fb = [b.load_packed12(f) for f in frames]
+        oa = a.tonemap_reinhard(fa, gamma=0.6)
+        ob = b.tonemap_reinhard(fb, gamma=0.6)
+        assert_close(b.metrics.cpu().numpy(), a.metrics.cpu().numpy(), f"metering state, call {step}", rel=1e-5)
+        for x, y in zip(oa, ob):
+            assert_close(y.cpu().numpy(), x.cpu().numpy(), f"u8 output, call {step}")
