@@ -47,7 +47,7 @@ class BatchPipeline:
 
     def __init__(self, n_frames, H, W, device, n_streams=4, pattern=BayerPattern.RGGB, ids_format=False,
                  correct_colors=None, work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0,
-                 light_adapt=1.0, color_adapt=0.0):
+                 light_adapt=1.0, color_adapt=0.0, use_graph=False):
         self.n_frames, self.H, self.W, self.device = n_frames, H, W, device
         self.work, self.odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
         self.pattern, self.ids = pattern, int(bool(ids_format))
@@ -59,11 +59,33 @@ class BatchPipeline:
         self.ws = torch.zeros(ws_bytes * n_frames, dtype=torch.uint8, device=device)
         self.outputs = [torch.empty((H, W, 3), dtype=self.odt.torch, device=device) for _ in range(n_frames)]
         self.out_ptrs = _native.ptr_array(self.outputs)
+        # use_graph: the step (fork to the worker streams, 4 launches per frame, join) is captured once
+        # into a HIP graph and replayed while the input tensors keep their addresses (a ring of
+        # upload buffers does); replay removes the launch gaps between the dependent kernels
+        self.use_graph = bool(use_graph)
+        self._graph, self._graph_key = None, None
 
-    def __call__(self, frames):
+    def __call__(self, frames, eager=False):
         assert len(frames) == self.n_frames
         for f in frames:
             assert _check_packed(f) == (self.H, self.W)
+        if self.use_graph and not eager:
+            key = tuple(f.data_ptr() for f in frames)
+            if self._graph is None or key != self._graph_key:
+                self._issue(frames)                          # warm (lazy initialisation stays out of the capture)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(cap):
+                    with torch.cuda.graph(g, stream=cap):
+                        self._issue(frames)
+                torch.cuda.synchronize(self.device)
+                self._graph, self._graph_key, self._graph_inputs = g, key, list(frames)   # keep the inputs alive
+            self._graph.replay()
+            return self.outputs
+        return self._issue(frames)
+
+    def _issue(self, frames):
         # the frames were produced on the current stream: make the worker streams wait for it
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:

@@ -330,6 +330,28 @@ def test_batch_pipeline_equals_single(ti, rng, dev):
         assert torch.equal(o, pipeline12_reinhard(f))
 
 
+def test_batch_pipeline_graph_replay(ti, rng, dev):
+    """use_graph: the captured step replays with new contents in the same input buffers, recaptures
+    when the buffers change, and an eager step in between gives the same results."""
+    from taichi_image_amd.pipeline import BatchPipeline, pipeline12_reinhard
+    H, W = 64, 128
+    host = [natural_packed12(rng, H, W) for _ in range(8)]
+    bufs = [torch.from_numpy(host[i]).to(dev) for i in range(4)]
+    bp = BatchPipeline(4, H, W, dev, n_streams=2, use_graph=True)
+    for round_ in range(3):
+        for i in range(4):
+            bufs[i].copy_(torch.from_numpy(host[(i + round_) % 8]))       # same addresses, new frames
+        outs = [o.clone() for o in bp(bufs, eager=(round_ == 1))]
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, pipeline12_reinhard(torch.from_numpy(host[(i + round_) % 8]).to(dev)))
+    other = [torch.from_numpy(host[4 + i]).to(dev) for i in range(4)]         # different buffers: recapture
+    outs = [o.clone() for o in bp(other)]
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, pipeline12_reinhard(other[i]))
+
+
 # ---------------------------------------------------------------------------------------------
 # camera_isp.py (stateful ISP)
 # ---------------------------------------------------------------------------------------------
