@@ -212,6 +212,7 @@ def main():
 
     from taichi_image_amd import _native
     import ctypes
+    bp.prepare(frames)                    # set-up (module load, graph capture), not a step
     for _ in range(args.warmup):
         bp(frames)
     barrier()

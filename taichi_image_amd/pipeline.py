@@ -85,6 +85,14 @@ class BatchPipeline:
             return self.outputs
         return self._issue(frames)
 
+    def prepare(self, frames):
+        """Set-up outside any timed region: library warm-up and (use_graph) the capture for these buffers."""
+        self._issue(frames)
+        torch.cuda.synchronize(self.device)
+        if self.use_graph:
+            self(frames)
+            torch.cuda.synchronize(self.device)
+
     def _issue(self, frames):
         # the frames were produced on the current stream: make the worker streams wait for it
         cur = torch.cuda.current_stream(self.device)
