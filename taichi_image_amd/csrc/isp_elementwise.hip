@@ -14,7 +14,7 @@ constexpr int EW_THREADS = 256;
 // RGB passes: few fat blocks (2 per CU), so that the per-block prologue that folds the previous
 // pass's partials (pull_finalize) reads little in total and leaves few partials itself
 constexpr int PASS_THREADS = 512;
-constexpr int PASS_MAX_BLOCKS = 512;
+constexpr int PASS_MAX_BLOCKS = 1024;              // capacity of the partial rows; pass_blocks() picks the grid
 
 static inline int grid_for(int64_t work_items, int cap = 256 * 16) {
   int64_t b = (work_items + EW_THREADS - 1) / EW_THREADS;
@@ -945,10 +945,16 @@ static int launch_pass_t(int mode, const PassArgs& a, int nblocks, hipStream_t s
 }
 
 // number of blocks an RGB pass over n_px pixels uses (== number of partials it leaves)
-static int pass_blocks(int64_t n_px, int cap) {
+// reduce_only: the statistics / bounds passes of the stateless chain run one block per CU (measured on a 4K
+// frame, blocks -> us for pass 1 / pass 2: 256 -> 16.0 / 21.2, 512 -> 16.7 / 22.6, 1024 -> 18.4 / 27.0: every
+// block pays the prologue that folds the previous pass's partials); the storing passes two per CU
+static int pass_blocks(int64_t n_px, int cap, bool reduce_only = false) {
   int64_t groups = (n_px + 7) / 8;
   int64_t b = (groups + PASS_THREADS - 1) / PASS_THREADS;
   if (b < 1) b = 1;
+  static const int env_limit = getenv("MI_ISP_PASS_BLOCKS") ? atoi(getenv("MI_ISP_PASS_BLOCKS")) : 0;   // measurement aid
+  const int limit = env_limit > 0 ? env_limit : (reduce_only ? 256 : 512);
+  if (b > limit) b = limit;
   if (b > PASS_MAX_BLOCKS) b = PASS_MAX_BLOCKS;
   if (b > cap) b = cap;
   return (int)b;
@@ -1009,7 +1015,7 @@ int tonemap_reinhard_tail(const void* src, void* dst, int H, int W, int in_dtype
   a.gamma_inv = 1.0f / gamma; a.la = la; a.ca = ca;
   a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
   a.pull_npx = (float)a.n_px; a.pull_intensity = intensity;
-  const int nb = pass_blocks(a.n_px, cap);
+  const int nb = pass_blocks(a.n_px, cap), nbr = pass_blocks(a.n_px, cap, true);
   // measurement aid: MI_ISP_PULL_DEBUG=0 runs single passes (which > 0) on the scalars a full run left
   // in FrameParams, without the pulled finalize
   static const char* dbg = getenv("MI_ISP_PULL_DEBUG");
@@ -1020,17 +1026,17 @@ int tonemap_reinhard_tail(const void* src, void* dst, int H, int W, int in_dtype
     p1.partials = stats_part; p1.part_stride = TAIL_STRIDE;
     p1.pull_mode = no_pull ? -1 : FIN_BOUNDS | dbg_bits; p1.pull_partials = bounds.partials; p1.pull_stride = bounds.stride;
     p1.pull_n = (dbg_bits & 0x200) ? 0 : bounds.n; p1.pull_bounds_post = bounds.bounds_post;
-    if (int rc = launch_pass(PM_STATS, in_dtype, out_dtype, p1, nb, s)) return rc;
+    if (int rc = launch_pass(PM_STATS, in_dtype, out_dtype, p1, nbr, s)) return rc;
   }
   if (which < 0 || which == 2) {                                                      // :150,153
     PassArgs p2 = a;
     p2.partials = bounds2_part; p2.part_stride = TAIL_STRIDE;
-    p2.pull_mode = no_pull ? -1 : FIN_STATS | dbg_bits; p2.pull_partials = stats_part; p2.pull_stride = TAIL_STRIDE; p2.pull_n = (dbg_bits & 0x200) ? 0 : nb;
-    if (int rc = launch_pass(PM_RH_MINMAX, in_dtype, out_dtype, p2, nb, s)) return rc;
+    p2.pull_mode = no_pull ? -1 : FIN_STATS | dbg_bits; p2.pull_partials = stats_part; p2.pull_stride = TAIL_STRIDE; p2.pull_n = (dbg_bits & 0x200) ? 0 : nbr;
+    if (int rc = launch_pass(PM_RH_MINMAX, in_dtype, out_dtype, p2, nbr, s)) return rc;
   }
   if (which < 0 || which == 3) {                                                      // :154
     PassArgs p3 = a;
-    p3.pull_mode = no_pull ? -1 : FIN_BOUNDS2 | dbg_bits; p3.pull_partials = bounds2_part; p3.pull_stride = TAIL_STRIDE; p3.pull_n = (dbg_bits & 0x200) ? 0 : nb;
+    p3.pull_mode = no_pull ? -1 : FIN_BOUNDS2 | dbg_bits; p3.pull_partials = bounds2_part; p3.pull_stride = TAIL_STRIDE; p3.pull_n = (dbg_bits & 0x200) ? 0 : nbr;
     if (int rc = launch_pass(PM_RH_STORE, in_dtype, out_dtype, p3, nb, s)) return rc;
   }
   return 0;
