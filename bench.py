@@ -161,11 +161,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per rank (frames in flight)")
-    ap.add_argument("--profile-every", type=int, default=2,
+    ap.add_argument("--profile-every", type=int, default=5,
                     help="HIP events around the passes of every n-th frame of the timed region")
-    ap.add_argument("--no-graph", action="store_true", help="issue every step launch by launch (no HIP graph replay)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as a captured HIP graph (+4-6 %% throughput, DESIGN.md 7).  Not the default: "
+                         "kernels inside a graph cannot be timed with events, so the per-pass durations would come "
+                         "from the few steps issued launch by launch (--eager-every) and stop agreeing with rocprofv3")
     ap.add_argument("--eager-every", type=int, default=10,
-                    help="with graph replay: every n-th step of the timed region is issued launch by launch so that "
+                    help="with --graph: every n-th step of the timed region is issued launch by launch so that "
                          "the per-pass events (--profile-every) can be recorded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2", "isp", "isp-shared-stats"],
@@ -202,7 +205,7 @@ def main():
     n_distinct = min(4, args.frames)
     host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(n_distinct)]
     frames = [torch.from_numpy(host[i % n_distinct]).to(device) for i in range(args.frames)]
-    bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams, use_graph=not args.no_graph)
+    bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams, use_graph=args.graph)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -220,7 +223,7 @@ def main():
     _native.check(_native.lib().mi_isp_profile_enable(args.frames * args.steps, args.profile_every))
     t0 = time.perf_counter()
     for step in range(args.steps):
-        bp(frames, eager=(step % max(1, args.eager_every) == 0))
+        bp(frames, eager=(not args.graph) or (step % max(1, args.eager_every) == 0))
     barrier()
     elapsed = time.perf_counter() - t0
     live_us, live_n = (ctypes.c_float * 4)(), ctypes.c_int(0)
@@ -259,7 +262,8 @@ def main():
             "config": {"workload": "config 2: 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap (stateless, "
                                    "gamma 1) -> f16 RGB", "frames_per_rank_per_step": args.frames,
                        "streams_per_rank": args.streams, "work_dtype": "f16",
-                       "launch": ("eager" if args.no_graph else f"HIP graph replay of the step; every {args.eager_every}th step eager for the per-pass events"), "sharding": f"frames x{world}, no collective"},
+                       "launch": (f"HIP graph replay of the step; every {args.eager_every}th step launch by launch for the per-pass events"
+                                  if args.graph else "launch by launch"), "sharding": f"frames x{world}, no collective"},
             "us_per_frame": round(elapsed / (args.frames * args.steps) * 1e6, 2),
             "pipeline_frac_of_hbm_roofline": round(ALG_BYTES * world * args.frames * args.steps / elapsed / 1e9
                                                    / (HBM_PEAK_GBS * world), 4),
