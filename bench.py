@@ -45,7 +45,7 @@ PASS_NAMES = ["pass0: tile_kernel<f16,RGGB,EPI_STORE_MINMAX> (unpack + demosaic 
               "pass3: rgb_pass_kernel<f16,f16,PM_RH_STORE> (final map, in place)"]
 
 
-def time_passes(frame, out, ws_ptr, device, reps=30):
+def time_passes(frame, out, ws_ptr, device, reps=10):
     """Average duration (us) of each data pass, events on the stream the kernels run on."""
     from taichi_image_amd import _native, types
     L = _native.lib()
@@ -56,7 +56,7 @@ def time_passes(frame, out, ws_ptr, device, reps=30):
             _native.check(L.mi_isp_pipeline12_pass(frame.data_ptr(), out.data_ptr(), H, W, 0, 0, None,
                                                    types.f16.code, types.f16.code, 1.0, 1.0, 0.0, p, ws_ptr,
                                                    stream.cuda_stream))
-        for _ in range(5):
+        for _ in range(2):
             launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
