@@ -476,6 +476,36 @@ MI_DEV void wave_store_row(T* dst, int W, int row0, int c0, int lane, void* stag
   __builtin_amdgcn_wave_barrier();
 }
 
+// clamp(x, 0, 1) (bayer.py:155) and the RNE conversion to f16 of two values in ONE instruction: the clamp
+// output modifier of v_cvt_pk_f16_f32 (rounding is monotone and 0, 1 are representable, so clamping the
+// rounded value equals rounding the clamped one; NaN -> 0 like clamp01).  Replaces 2 v_max..clamp + 1 v_cvt_pk.
+MI_DEV uint32_t cvt_pk_f16_clamp01(float a, float b) {
+  uint32_t r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// wave_store_row for f16 outputs from UNCLAMPED fp32 values (the HOT kernels with unit scale)
+MI_DEV void wave_store_row_f16_clamped(half_t* dst, int W, int row0, int c0, int lane, void* stage, const float (&v)[24]) {
+  uint4 mine[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    mine[j] = make_uint4(cvt_pk_f16_clamp01(v[8 * j], v[8 * j + 1]), cvt_pk_f16_clamp01(v[8 * j + 2], v[8 * j + 3]),
+                         cvt_pk_f16_clamp01(v[8 * j + 4], v[8 * j + 5]), cvt_pk_f16_clamp01(v[8 * j + 6], v[8 * j + 7]));
+  uint4* lb = static_cast<uint4*>(stage);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) lb[lane * 3 + j] = mine[j];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = j * 64 + lane;                       // unit index in the wave's 4 x 48 units
+    const int sgm = (q >= 48) + (q >= 96) + (q >= 144);
+    uint4* g = reinterpret_cast<uint4*>(dst + ((size_t)(row0 + 2 * sgm) * W + c0) * 3) + (q - 48 * sgm);
+    *g = lb[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], int npx) {
   if (p.debug_skip & 32) {                      // measurement aid: no global stores
     float s = 0.f;
@@ -684,6 +714,18 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
               vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
             }
           }
+        } else if constexpr ((EPI == EPI_STORE || EPI == EPI_STORE_MINMAX) && (HOT == 1 || HOT == 2) && sizeof(E) == 2) {
+          // f16 image with unit scale: clamp and conversion are one instruction per pixel pair; the bounds
+          // are reduced on the unclamped fp32 values (clamp and rounding are monotone: finalize applies them)
+          if constexpr (EPI == EPI_STORE_MINMAX) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              vmin = fminf(vmin, fminf(v[3 * k], fminf(v[3 * k + 1], v[3 * k + 2])));
+              vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
+            }
+          }
+          wave_store_row_f16_clamped(static_cast<half_t*>(p.dst), p.W, r0 + 8 * (threadIdx.x >> 6) + i, c0,
+                                     threadIdx.x & 63, stage, v);
         } else {
 #pragma unroll
           for (int j = 0; j < 24; ++j) v[j] = clamp01(v[j]);                       // bayer.py:155
