@@ -147,8 +147,7 @@ __global__ __launch_bounds__(THREADS) void resize_tile_kernel(const RParams rp_i
       uint32_t v[8];
       tile::unpack12x8(raw[it][0], raw[it][1], raw[it][2], false, v);
       float out[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = tile::decode_scaled<E>(v[i], p.k_decode);
+      tile::decode_scaled8<E>(v, p.k_decode, out);
       float* d = lds + lr * PITCH + lu * 8;
       *reinterpret_cast<float4*>(d) = make_float4(out[0], out[1], out[2], out[3]);
       *reinterpret_cast<float4*>(d + 4) = make_float4(out[4], out[5], out[6], out[7]);
@@ -195,8 +194,7 @@ __global__ __launch_bounds__(THREADS) void resize_tile_kernel(const RParams rp_i
         }
       }
       float out[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = tile::decode_scaled<E>(v[i], p.k_decode);
+      tile::decode_scaled8<E>(v, p.k_decode, out);
       float* d = lds + lr * PITCH + lu * 8;
       *reinterpret_cast<float4*>(d) = make_float4(out[0], out[1], out[2], out[3]);
       *reinterpret_cast<float4*>(d + 4) = make_float4(out[4], out[5], out[6], out[7]);

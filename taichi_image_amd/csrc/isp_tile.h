@@ -184,6 +184,25 @@ MI_DEV void unpack12x8(uint32_t d0, uint32_t d1, uint32_t d2, bool ids, uint32_t
 // scaled write of packed.py:98-100, cast(f32(v) * f32(scale/4095), E), widened back to fp32
 template <class E> MI_DEV float decode_scaled(uint32_t v, float k) { return (float)cast_out<E>((float)v * k); }
 
+// 8 values at once; for the f16 work type the products are rounded in pairs (v_cvt_pk_f16_f32: the same
+// RNE conversion of the same fp32 products, half the conversion instructions) and widened back
+template <class E> MI_DEV void decode_scaled8(const uint32_t (&v)[8], float k, float (&out)[8]) {
+  if constexpr (sizeof(E) == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = (float)v[2 * i] * k, b = (float)v[2 * i + 1] * k;
+      uint32_t pk;
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+      half_t h[2];
+      __builtin_memcpy(h, &pk, 4);
+      out[2 * i] = (float)h[0]; out[2 * i + 1] = (float)h[1];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = decode_scaled<E>(v[i], k);
+  }
+}
+
 // one 8-px unit (LDS columns 8*lu .. 8*lu+7) = even slot 2*lu and odd slot 2*lu+1 of the row
 MI_DEV void lds_store8(float* row, int lu, const float (&v)[8]) {
   *reinterpret_cast<float4*>(row + 4 * lu) = make_float4(v[0], v[1], v[2], v[3]);
@@ -275,8 +294,7 @@ MI_DEV void fill_packed_fast(const Params& p, float* lds, int rb, int cb) {
       v[4] = d.z & 0xFFFFu; v[5] = d.z >> 16; v[6] = d.w & 0xFFFFu; v[7] = d.w >> 16;
     }
     float out[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = decode_scaled<E>(v[i], p.k_decode);
+    decode_scaled8<E>(v, p.k_decode, out);
     lds_store8(lds + off[it], 0, out);
   }
 }
