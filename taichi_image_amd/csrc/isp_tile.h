@@ -471,25 +471,30 @@ MI_DEV void store_row(T* dst, const float (&v)[24], int npx, bool vec) {
 // transposed through `stage` (the wave's own slice of the CFA tile buffer, free once every wave has
 // its window) so that each store instruction writes long contiguous runs: 6.2 vs 3.7 TB/s measured
 // for the per-lane 3 x 16 B pattern (scratch/store_bench.hip).  T is 1 or 2 bytes wide.
+// 4-byte outputs have 6 units per lane: their LDS slots are padded to 7 per lane so that the 16-byte
+// writes of consecutive lanes fall into different bank groups (WAVE_STAGE_UNITS per wave).
+template <class T> struct StagePitch { static constexpr int value = IoUnits<T>::value == 6 ? 7 : IoUnits<T>::value; };
 template <class T>
 MI_DEV void wave_store_row(T* dst, int W, int row0, int c0, int lane, void* stage, const float (&v)[24]) {
   typedef typename IoUnit<T>::type U;
-  static_assert(IoUnits<T>::value == 3, "3 units per lane");
+  constexpr int N = IoUnits<T>::value, P = StagePitch<T>::value;
+  static_assert(N == 3 || N == 6, "3 or 6 units per lane");
   T o[24];
 #pragma unroll
   for (int i = 0; i < 24; ++i) o[i] = cast_out<T>(v[i]);
-  U mine[3];
+  U mine[N];
   __builtin_memcpy(mine, o, sizeof(mine));
   U* lb = static_cast<U*>(stage);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) lb[lane * 3 + j] = mine[j];
+  for (int j = 0; j < N; ++j) lb[lane * P + j] = mine[j];
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int q = j * 64 + lane;                       // unit index in the wave's 4 x 48 units
-    const int sgm = (q >= 48) + (q >= 96) + (q >= 144);
-    U* g = reinterpret_cast<U*>(dst + ((size_t)(row0 + 2 * sgm) * W + c0) * 3) + (q - 48 * sgm);
-    *g = lb[q];
+  for (int j = 0; j < N; ++j) {
+    const int q = j * 64 + lane;                       // unit index in the wave's 4 segments x 16 N units
+    const int sgm = (q >= 16 * N) + (q >= 32 * N) + (q >= 48 * N);
+    U* g = reinterpret_cast<U*>(dst + ((size_t)(row0 + 2 * sgm) * W + c0) * 3) + (q - 16 * N * sgm);
+    const int src_lane = (N == 3) ? 0 : q / N;         // N == 3: slot index == q
+    *g = (N == 3) ? lb[q] : lb[src_lane * P + (q - src_lane * N)];
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -575,7 +580,12 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
     p.in_scale = HOT == 3 ? ScaleOf<CfaT>::value : 1.f;
     p.out_dtype = cfa_code; p.out_scale = p.in_scale;
   }
-  __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * PITCH];
+  // the tile buffer doubles as the per-wave staging of the cooperative stores; 4-byte outputs of the
+  // specialised kernels need 64 lanes x 7 units x 16 B per wave
+  constexpr bool STAGE_F32 = (HOT == 1 || HOT == 2) && sizeof(E) == 4;
+  constexpr int WAVE_STAGE_FLOATS = STAGE_F32 ? 64 * 7 * 4 : 64 * 12;
+  constexpr int LDS_FLOATS = LDS_ROWS * PITCH > 4 * WAVE_STAGE_FLOATS ? LDS_ROWS * PITCH : 4 * WAVE_STAGE_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   __shared__ float red[4][8];
 
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8).  With a row-major tile order
@@ -624,11 +634,11 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   float win[6][12];
   if (active) load_window(lds, tx, ty, win);
   // a full tile with 1/2-byte outputs is stored wave-cooperatively through the (now free) tile buffer
-  const bool coop_store = STORES && p.out_dtype != MI_F32 &&
+  const bool coop_store = STORES && (STAGE_F32 || p.out_dtype != MI_F32) &&
                           (HOT != 0 || (p.vec_store && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W && !(p.debug_skip & 32)));
   if (STORES) __syncthreads();                          // every wave holds its window
   MI_STAMP(3);
-  void* stage = lds + (threadIdx.x >> 6) * (64 * 12);   // 3 KB per wave
+  void* stage = lds + (threadIdx.x >> 6) * WAVE_STAGE_FLOATS;   // 3 KB (7 KB for 4-byte outputs) per wave
   if (active) {
     // every tap of all 16 pixels in bounds, and c / (in_scale * t) == c / 16 ?
     const bool fast = p.in_scale == 1.f && r >= 2 && r + 1 < p.H - 2 && c >= 2 && c + 7 < p.W - 2;
@@ -712,6 +722,9 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
           switch (p.out_dtype) {
             case MI_U8: wave_store_row<uint8_t>(static_cast<uint8_t*>(p.dst), p.W, row0, c0, lane, stage, vals); break;
             case MI_U16: wave_store_row<uint16_t>(static_cast<uint16_t*>(p.dst), p.W, row0, c0, lane, stage, vals); break;
+            case MI_F32:
+              if constexpr (STAGE_F32) wave_store_row<float>(static_cast<float*>(p.dst), p.W, row0, c0, lane, stage, vals);
+              break;
             default: wave_store_row<half_t>(static_cast<half_t*>(p.dst), p.W, row0, c0, lane, stage, vals); break;
           }
         } else {
