@@ -553,7 +553,7 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 // ---------------------------------------------------------------------------------------------
 // HOT: the configuration of the packed-RAW pipelines, fixed at compile time so that the kernel is
 // straight-line code without the generic paths: standard 12-bit packing with aligned rows, whole
-// tile columns and whole waves (W % 128 == 0, H % 8 == 0), no colour matrix, stores in the work dtype (see hot_spec); HOT == 2: the same for a plain f16 / f32 CFA image.
+// 8-pixel strips (W % 8 == 0; ragged right / bottom tiles store per lane), no colour matrix, stores in the work dtype (see hot_spec); HOT == 2: the same for a plain f16 / f32 CFA image.
 // measurement aid (make EXTRA=-DMI_TILE_STAMPS): wave 0 of every block leaves s_memtime stamps of its
 // phases in workspace rows 2.. (32-bit, 8 per block); see scripts/tile_stamps.py
 #ifdef MI_TILE_STAMPS
@@ -612,8 +612,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
 
   const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
   const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
-  // H, W even -> both rows, pixel pairs in.  HOT: whole tile columns; H % 8 == 0, so a wave (8 rows) is all in or all out
-  const bool active = HOT != 0 ? r < p.H : (r < p.H && c < p.W && !(p.debug_skip & 2));
+  // H, W even -> both rows, pixel pairs in.  HOT: W % 8 == 0, so a strip is all in or all out
+  const bool active = r < p.H && c < p.W && (HOT != 0 || !(p.debug_skip & 2));
   const int npx = HOT != 0 ? 8 : (active ? (p.W - c < 8 ? p.W - c : 8) : 0);
 
   // tonemap scalars (uniform loads); unused ones are dead code per EPI
@@ -634,8 +634,8 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   float win[6][12];
   if (active) load_window(lds, tx, ty, win);
   // a full tile with 1/2-byte outputs is stored wave-cooperatively through the (now free) tile buffer
-  const bool coop_store = STORES && (STAGE_F32 || p.out_dtype != MI_F32) &&
-                          (HOT != 0 || (p.vec_store && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W && !(p.debug_skip & 32)));
+  const bool coop_store = STORES && (STAGE_F32 || p.out_dtype != MI_F32) && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W &&
+                          (HOT != 0 || (p.vec_store && !(p.debug_skip & 32)));
   if (STORES) __syncthreads();                          // every wave holds its window
   MI_STAMP(3);
   void* stage = lds + (threadIdx.x >> 6) * WAVE_STAGE_FLOATS;   // 3 KB (7 KB for 4-byte outputs) per wave
@@ -755,8 +755,14 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
               vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
             }
           }
-          wave_store_row_f16_clamped(static_cast<half_t*>(p.dst), p.W, r0 + 8 * (threadIdx.x >> 6) + i, c0,
-                                     threadIdx.x & 63, stage, v);
+          if (coop_store) {                               // block-uniform: whole tile
+            wave_store_row_f16_clamped(static_cast<half_t*>(p.dst), p.W, r0 + 8 * (threadIdx.x >> 6) + i, c0,
+                                       threadIdx.x & 63, stage, v);
+          } else {                                        // ragged right / bottom tile: per-lane vector stores
+#pragma unroll
+            for (int j = 0; j < 24; ++j) v[j] = clamp01(v[j]);
+            store_row_dyn(p, r + i, c, v, 8);
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 24; ++j) v[j] = clamp01(v[j]);                       // bayer.py:155
@@ -852,10 +858,10 @@ static inline int launch(const Params& p, int work_dtype, int pattern, int epi, 
 
 // which compile-time specialisation (template parameter HOT) may this launch of epilogue `epi` use?
 // 0: none; 1: packed 12-bit source (standard layout, aligned rows); 2: plain f16 / f32 CFA of the work
-// dtype with 16-byte aligned rows; 3: u8 / u16 CFA, same dtype out.  All: whole tiles, no colour matrix.
+// dtype with 16-byte aligned rows; 3: u8 / u16 CFA, same dtype out.  All: W % 8 == 0, no colour matrix.
 static inline int hot_spec(const Params& p, int work_dtype, int epi) {
   const bool stores = epi == EPI_STORE || epi == EPI_STORE_MINMAX;
-  const bool common = stores && !p.has_ccm && p.debug_skip == 0 && p.W % TILE_W == 0 && p.H % 8 == 0 && p.vec_store;
+  const bool common = stores && !p.has_ccm && p.debug_skip == 0 && p.W % 8 == 0 && p.vec_store;
   if (!common) return 0;
   const bool unit = p.in_scale == 1.f && p.out_scale == 1.f && p.out_dtype == work_dtype;
   if (unit && p.src_kind == SRC_PACKED12 && p.src_fast) return 1;
