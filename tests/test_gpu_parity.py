@@ -319,6 +319,19 @@ def test_pipeline12_4k_against_c_oracle(ti, dev):
     assert_close(got8, c_oracle.pipeline12_reinhard(packed, out="u8", gamma=0.6), "pipeline12 4K u8 vs C oracle")
 
 
+def test_pipeline12_5mp_sensor_against_c_oracle(ti, dev):
+    """A 2448 x 2048 sensor: the width is a multiple of 8 but not of the 128-pixel tile, the height not of 32 -
+    the specialised kernels with ragged right / bottom tiles, against the C oracle."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/liborc_isp.so not built")
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    from taichi_image_amd.synthetic import synthetic_packed12
+    packed = synthetic_packed12(5, 2050, 2448)
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev)).cpu().numpy()
+    assert_close(got, c_oracle.pipeline12_reinhard(packed), "pipeline12 2448x2050 vs C oracle")
+
+
 def test_batch_pipeline_equals_single(ti, rng, dev):
     from taichi_image_amd.pipeline import BatchPipeline, pipeline12_reinhard
     H, W = 64, 128
