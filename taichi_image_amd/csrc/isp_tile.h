@@ -553,7 +553,7 @@ MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], i
 // ---------------------------------------------------------------------------------------------
 // HOT: the configuration of the packed-RAW pipelines, fixed at compile time so that the kernel is
 // straight-line code without the generic paths: standard 12-bit packing with aligned rows, whole
-// 8-pixel strips (W % 8 == 0; ragged right / bottom tiles store per lane), no colour matrix, stores in the work dtype (see hot_spec); HOT == 2: the same for a plain f16 / f32 CFA image.
+// 8-pixel strips (W % 8 == 0; ragged right / bottom tiles store per lane), stores in the work dtype (see hot_spec); HOT == 2: the same for a plain f16 / f32 CFA image.
 // measurement aid (make EXTRA=-DMI_TILE_STAMPS): wave 0 of every block leaves s_memtime stamps of its
 // phases in workspace rows 2.. (32-bit, 8 per block); see scripts/tile_stamps.py
 #ifdef MI_TILE_STAMPS
@@ -575,8 +575,9 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   typedef typename std::conditional<HOT == 3, typename std::conditional<sizeof(E) == 2, uint8_t, uint16_t>::type, E>::type CfaT;
   if constexpr (HOT != 0) {
     constexpr int cfa_code = HOT == 3 ? (sizeof(E) == 2 ? (int)MI_U8 : (int)MI_U16) : dtype_code<E>();
-    p.src_kind = HOT == 1 ? (int)SRC_PACKED12 : cfa_code;              // SRC_CFA_* share the MI_* numbering
-    p.src_fast = 1; p.has_ccm = 0; p.debug_skip = 0; p.vec_store = 1;
+    // SRC_CFA_* share the MI_* numbering; HOT == 1 keeps the two 12-bit layouts (standard / IDS) a run-time flag
+    p.src_kind = HOT == 1 ? (p.src_kind == SRC_PACKED12_IDS ? (int)SRC_PACKED12_IDS : (int)SRC_PACKED12) : cfa_code;
+    p.src_fast = 1; p.debug_skip = 0; p.vec_store = 1;      // the colour matrix stays a run-time (uniform) branch
     p.in_scale = HOT == 3 ? ScaleOf<CfaT>::value : 1.f;
     p.out_dtype = cfa_code; p.out_scale = p.in_scale;
   }
@@ -858,13 +859,13 @@ static inline int launch(const Params& p, int work_dtype, int pattern, int epi, 
 
 // which compile-time specialisation (template parameter HOT) may this launch of epilogue `epi` use?
 // 0: none; 1: packed 12-bit source (standard layout, aligned rows); 2: plain f16 / f32 CFA of the work
-// dtype with 16-byte aligned rows; 3: u8 / u16 CFA, same dtype out.  All: W % 8 == 0, no colour matrix.
+// dtype with 16-byte aligned rows; 3: u8 / u16 CFA, same dtype out.  All: W % 8 == 0.
 static inline int hot_spec(const Params& p, int work_dtype, int epi) {
   const bool stores = epi == EPI_STORE || epi == EPI_STORE_MINMAX;
-  const bool common = stores && !p.has_ccm && p.debug_skip == 0 && p.W % 8 == 0 && p.vec_store;
+  const bool common = stores && p.debug_skip == 0 && p.W % 8 == 0 && p.vec_store;
   if (!common) return 0;
   const bool unit = p.in_scale == 1.f && p.out_scale == 1.f && p.out_dtype == work_dtype;
-  if (unit && p.src_kind == SRC_PACKED12 && p.src_fast) return 1;
+  if (unit && (p.src_kind == SRC_PACKED12 || p.src_kind == SRC_PACKED12_IDS) && p.src_fast) return 1;
   if (epi != EPI_STORE || ((uintptr_t)p.src & 15) != 0) return 0;
   if (unit && p.src_kind == work_dtype && (work_dtype == MI_F16 || work_dtype == MI_F32)) return 2;
   // 3: integer CFA (u8 with the f16 work type, u16 with f32), same dtype out
