@@ -71,11 +71,11 @@ def time_passes(frame, out, ws_ptr, device, reps=10):
 def cpu_baseline(packed_frame: np.ndarray):
     """The CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
     ncores = os.cpu_count() or 1
-    # the GPU box gives one GPU a share of 16 host cores; stay inside it
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(ncores, 16)))
     try:
         from oracle import c_oracle
         if c_oracle.available():
+            # the GPU box gives one GPU a share of 16 host cores; stay inside it
+            c_oracle.set_threads(min(ncores, 16))
             reps, times = 3, []
             for _ in range(reps):
                 t0 = time.perf_counter()

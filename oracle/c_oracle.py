@@ -28,6 +28,10 @@ def threads() -> int:
     return int(lib().orc_threads())
 
 
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(ctypes.c_int(int(n)))
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 

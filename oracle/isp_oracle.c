@@ -63,6 +63,15 @@ int orc_threads(void) {
 #endif
 }
 
+/* limit the OpenMP team (the GPU box gives one GPU a share of 16 host cores) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 uint16_t orc_f32_to_f16_bits(float f) { return f32_to_f16_bits(f); }
 
 /* ---- packed.py:24-31 (standard), :37-44 (IDS) ------------------------------------------------ */
