@@ -284,6 +284,28 @@ def test_pipeline12_params_and_ccm(ti, rng, dev):
     assert_close(got, ref, "pipeline12 ccm+params")
 
 
+def test_specialised_kernels_random_shapes(ti, dev):
+    """The compile-time specialisations (packed / plain CFA sources, ragged right and bottom tiles, IDS layout,
+    colour matrix) against the NumPy oracle on random even heights and widths that are multiples of 8, plus the
+    neighbouring widths that fall back to the generic kernel."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    r = np.random.default_rng(77)
+    ccm = O.isp_color_matrix(True, O.DEFAULT_WB, O.DEFAULT_CC)
+    for trial in range(24):
+        H = int(r.integers(1, 50)) * 2
+        W = int(r.integers(1, 40)) * 8 + (2 if trial % 6 == 5 else 0)          # every 6th: not a multiple of 8
+        p = int(r.integers(0, 4)); ids = bool(r.integers(0, 2)); use_ccm = trial % 3 == 0
+        packed = natural_packed12(r, H, W, pattern=p, ids_format=ids)
+        cc = ccm if use_ccm else None
+        got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), pat(ti, p), ids, correct_colors=cc).cpu().numpy()
+        assert_close(got, O.pipeline12_reinhard(packed, p, ids, cc), f"pipeline12 {H}x{W} p{p} ids={ids} ccm={use_ccm}")
+        # demosaic alone: bit-exact, f16 CFA and u16 CFA
+        cfa = random_cfa(r, H, W, "f16")
+        assert_exact(ti.bayer.bayer_to_rgb(cfa, pat(ti, p)), O.bayer_to_rgb(cfa, p), f"demosaic f16 {H}x{W} p{p}")
+        cfa16 = random_cfa(r, H, W, "u16")
+        assert_exact(ti.bayer.bayer_to_rgb(cfa16, pat(ti, p)), O.bayer_to_rgb(cfa16, p), f"demosaic u16 {H}x{W} p{p}")
+
+
 def test_pipeline12_matches_unfused_chain_4k(ti, dev):
     """Full BASELINE size: the fused four-pass pipeline against the unfused GPU chain
     decode12 -> bayer_to_rgb -> tonemap_reinhard (each parity-tested against the oracle above),
