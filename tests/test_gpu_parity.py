@@ -418,6 +418,23 @@ def test_isp_load_packed12_fused_resize(ti, rng, dev, p, shape, kw):
     assert_exact(got.cpu().numpy(), ref, f"fused resize {shape} p{p} {kw}")
 
 
+def test_isp_load_packed12_random_scales(ti, dev):
+    """Camera16 / Camera32 load_packed12 with random sizes, patterns and scales (fused kernel where the scale
+    fits, the unfused chain elsewhere), bit-exact against the oracle."""
+    r = np.random.default_rng(99)
+    for trial in range(12):
+        H = int(r.integers(8, 60)) * 2
+        W = int(r.integers(4, 30)) * 8 + (2 * int(r.integers(0, 4)) if trial % 4 == 3 else 0)
+        p = int(r.integers(0, 4))
+        scale = float(np.float32(r.uniform(0.25, 1.6)))
+        work, cam = (("f16", "Camera16") if trial % 3 else ("f32", "Camera32"))
+        packed = natural_packed12(r, H, W, pattern=p)
+        isp = getattr(ti, cam)(pat(ti, p), device=dev, scale=scale)
+        got = isp.load_packed12(torch.from_numpy(packed).to(dev))
+        ref = O.isp_load_packed12(packed, work, p, scale=scale)
+        assert_exact(got.cpu().numpy(), ref, f"{cam} load_packed12 {H}x{W} p{p} scale={scale}")
+
+
 def test_isp_load_packed12_config3_full_size(ti, dev):
     """BASELINE config 3: 4096x3072 packed-12 -> Camera16(resize_width=1920) -> f16 (1440, 1920, 3)."""
     from oracle import c_oracle
