@@ -247,6 +247,18 @@ def test_tonemap_reinhard(ti, rng, din, dout, params):
     assert_close(got, O.tonemap_reinhard(img, dtype=dout, **params), f"tonemap_reinhard {din}->{dout} {params}")
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (302, 518), (1080, 1920)])
+def test_tonemap_reinhard_multi_block(ti, rng, shape):
+    """Sizes with many blocks per pass (and an odd pixel count): every pass folds the previous pass's per-block
+    partials in its prologue, so the block count of the producer and the grid of the consumer both vary."""
+    img = _rgb_image(rng, shape[0], shape[1], "f32").astype(np.float16)
+    for dout, params in (("f16", dict()), ("u8", dict(gamma=0.6, intensity=1.3, light_adapt=0.9, color_adapt=0.2))):
+        got = ti.tonemap.tonemap_reinhard(img, dtype=tok(ti, dout), **params)
+        assert_close(got, O.tonemap_reinhard(img, dtype=dout, **params), f"tonemap_reinhard {shape} -> {dout}")
+    got = ti.tonemap.tonemap_linear(img, gamma=0.8, dtype=tok(ti, "u8"))
+    assert_close(got, O.tonemap_linear(img, 0.8, "u8"), f"tonemap_linear {shape}")
+
+
 def test_tonemap_reinhard_black_pixels(ti, rng):
     """All-black pixels give 0 * inf = NaN inside the reference formula (light_adapt = 1); the
     library defines NaN -> 0 at the output cast and ignores NaN in the reductions."""
