@@ -339,6 +339,25 @@ def test_pipeline12_matches_unfused_chain_4k(ti, dev):
     assert float(fused.float().min()) == 0.0 and float(fused.float().max()) == 1.0
 
 
+def test_pipeline12_50mp_matches_unfused_chain(ti, dev):
+    """8192 x 6144: more tiles than the 4096-entry floor of the partial rows (the workspace layout scales with
+    the tile count) - fused pipeline against the unfused GPU chain, u8 output (recompute variant) as well."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    from taichi_image_amd.synthetic import synthetic_packed12
+    small = synthetic_packed12(2, 1536, 2048)
+    packed = np.tile(small, (4, 4))                        # periodic 50 MP frame, cheap to build
+    pk = torch.from_numpy(packed).to(dev)
+    fused = pipeline12_reinhard(pk)
+    rgb = ti.bayer.bayer_to_rgb(ti.packed.decode12(pk, ti.types.f16, scaled=True))
+    unfused = ti.tonemap.tonemap_reinhard(rgb, dtype=ti.types.f16)
+    assert fused.shape == (6144, 8192, 3)
+    assert torch.equal(fused, unfused)
+    fused8 = pipeline12_reinhard(pk, dtype=ti.types.u8, gamma=0.6)
+    unfused8 = ti.tonemap.tonemap_reinhard(rgb, gamma=0.6, dtype=ti.types.u8)
+    diff = (fused8.int() - unfused8.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
+
+
 def test_pipeline12_4k_against_c_oracle(ti, dev):
     """Full BASELINE size against the CPU oracle (the C/OpenMP restatement, ~1 s per frame)."""
     from oracle import c_oracle
