@@ -171,10 +171,11 @@ int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed_host, void* co
 
 
 /* ---- measurement aid ----------------------------------------------------------------------- */
-/* Launches ONE data pass (0 = bounds, 1 = metering sums, 2 = Reinhard bounds, 3 = final map +
- * store) of mi_isp_pipeline12_reinhard without the finalize kernels, so that bench.py can time
- * the dominant kernel with events on its own stream.  ws_dev must hold the scalars left by a
- * previous full mi_isp_pipeline12_reinhard call on the same frame. */
+/* Launches ONE data pass (0 = demosaic + bounds, 1 = metering sums, 2 = Reinhard bounds, 3 = final
+ * map + store) of mi_isp_pipeline12_reinhard, so that bench.py can time each kernel in isolation with
+ * events on its own stream.  ws_dev must hold the scalars and per-block partials left by a previous
+ * full mi_isp_pipeline12_reinhard call on the same frame (passes 1-3 fold their predecessor's
+ * partials in their prologue). */
 int mi_isp_pipeline12_pass(const uint8_t* packed_dev, void* out_dev, int H, int W, int ids_format,
                            int pattern, const float* ccm9_host, int work_dtype, int out_dtype,
                            float gamma, float light_adapt, float color_adapt, int pass,

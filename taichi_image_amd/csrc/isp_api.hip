@@ -170,7 +170,8 @@ static PassTimer pass_timer(hipStream_t s) {
   return t;
 }
 
-// One frame of the fused config-2 chain: four tile passes + three finalize launches.
+// One frame of the fused config-2 chain, recompute variant (output dtype != work dtype): four tile passes over
+// the packed frame + three finalize launches.
 static int pipeline_frame(tile::Params p, int pattern, int work_dtype, float intensity, float* ws, hipStream_t s) {
   float* fp = ws;
   float* partials = ws + FP_COUNT;

@@ -198,7 +198,8 @@ MI_DEV void wave_store24(T* gptr, int lane, void* lbuf_, const T (&t)[24]) {
 }
 
 // ---- per-frame workspace layout (floats) ---------------------------------------------------------
-// [0, 64)            : FrameParams -- scalars produced by the finalize kernels, read by later passes
+// [0, 64)            : FrameParams -- scalars produced by the finalize steps (finalize_kernel, or pulled into the
+//                      consuming pass's prologue), read by later passes
 // [64, 64 + 8*cap)   : per-block partials, SoA: partial[k][block]
 enum {
   FP_LO = 0, FP_HI = 1, FP_INV = 2,                 // bounds of the input image, 1/(hi-lo)

@@ -2,7 +2,9 @@
 
     decode12(packed, dtype=work, scaled=True) -> bayer_to_rgb -> tonemap_reinhard(dtype=out)
 
-as four tile passes over the packed frame (csrc/isp_api.hip: pipeline_frame).  Results are
+as four data passes (csrc/isp_api.hip: pipeline_frame_cached when the output has the work dtype - one
+tile pass that writes the demosaiced image into the output buffer, three elementwise passes on it -
+and pipeline_frame, four tile passes over the packed frame, otherwise).  Results are
 identical to calling packed.decode12 / bayer.bayer_to_rgb / tonemap.tonemap_reinhard in turn.
 """
 from __future__ import annotations
@@ -43,7 +45,7 @@ class BatchPipeline:
     """Independent frames, one frame per HIP stream in flight (BASELINE config 4 on one GPU).
 
     Owns `n_streams` streams, the per-frame workspaces and the output tensors so that a step is
-    one C call issuing 7 launches per frame with no allocation on the way."""
+    one C call issuing 4 launches per frame (7 on the recompute variant) with no allocation on the way."""
 
     def __init__(self, n_frames, H, W, device, n_streams=4, pattern=BayerPattern.RGGB, ids_format=False,
                  correct_colors=None, work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0,
