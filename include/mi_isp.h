@@ -154,16 +154,21 @@ int mi_isp_load_packed(const uint8_t* packed_dev, void* rgb_dev, int H, int W, i
  * call mi_isp_resize_bilinear. */
 int mi_isp_load_packed_scale_supported(float scale);
 /* The stateless chain of test/pipeline.py:26-32 (BASELINE config 2) fused:
- * decode12(scaled, work_dtype) -> bayer_to_rgb -> tonemap_reinhard(dtype=out_dtype), four
- * passes over the packed frame, the only HBM traffic being packed-in and RGB-out. */
-int mi_isp_pipeline12_reinhard(const uint8_t* packed_dev, void* out_dev, int H, int W,
+ * decode12(scaled, work_dtype) -> bayer_to_rgb -> tonemap_reinhard(dtype=out_dtype) in four data passes.
+ * The demosaiced work-dtype image is kept between the passes in out_dev itself when out_dtype ==
+ * work_dtype, else in work_image_dev (H * W * 3 work-dtype elements, 16-byte aligned, caller-owned scratch);
+ * with work_image_dev == NULL and different dtypes every pass re-derives it from the packed frame
+ * (minimal HBM traffic, about 1.5x the time). */
+int mi_isp_pipeline12_reinhard(const uint8_t* packed_dev, void* out_dev, void* work_image_dev, int H, int W,
                                int ids_format, int pattern, const float* ccm9_host,
                                int work_dtype, int out_dtype, float gamma, float intensity,
                                float light_adapt, float color_adapt, void* ws_dev, void* stream);
 /* The same for n_frames independent frames, frame i on streams_host[i % n_streams]
- * (one frame per stream in flight); ws_dev holds n_frames consecutive workspaces. */
+ * (one frame per stream in flight); ws_dev holds n_frames consecutive workspaces;
+ * work_images_host: one scratch image per frame, or NULL. */
 int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed_host, void* const* out_host,
-                                     int n_frames, int H, int W, int ids_format, int pattern,
+                                     void* const* work_images_host, int n_frames, int H, int W,
+                                     int ids_format, int pattern,
                                      const float* ccm9_host, int work_dtype, int out_dtype,
                                      float gamma, float intensity, float light_adapt,
                                      float color_adapt, void* ws_dev, void* const* streams_host,

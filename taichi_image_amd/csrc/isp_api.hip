@@ -201,12 +201,16 @@ static int pipeline_frame(tile::Params p, int pattern, int work_dtype, float int
 // place.  One demosaic instead of four (the path is vector-issue-bound) at the price
 // of re-reading the 6 B/px image three times (it stays resident in the 256 MB Infinity Cache).
 // which: -1 = the whole chain; 0..3 = only that data pass (measurement aid).
+// `image`: where the work-dtype image lives between the passes (H * W * 3 work-dtype elements) - the output
+// buffer itself when the output has the work dtype, a caller-provided buffer otherwise; `out` / `out_dtype`:
+// the final destination of pass 3.
 static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, float gamma, float intensity,
-                                 float* ws, int which, hipStream_t s) {
+                                 float* ws, int which, hipStream_t s, void* image, void* out, int out_dtype) {
   float* fp = ws;
   float* partials = ws + FP_COUNT;
   const int cap = mi_partial_cap(p.H, p.W);
   p.fp = fp; p.partials = partials; p.part_stride = cap;
+  p.dst = image; p.vec_store = vec_store_ok(image, p.W, work_dtype);
   p.out_dtype = work_dtype; p.out_scale = 1.f;
   const PassTimer tm = which < 0 ? pass_timer(s) : PassTimer{0, false, s};
   if (int rc = tm.begin(0)) return rc;
@@ -216,11 +220,11 @@ static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, fl
   if (which == 0) return 0;
   const ew::PullSrc bounds = {partials, cap, tile::num_tiles(p.H, p.W), work_dtype == MI_F16 ? 2 : 1};
   if (which > 0)
-    return ew::tonemap_reinhard_tail(p.dst, p.dst, p.H, p.W, work_dtype, work_dtype, gamma, intensity, p.la, p.ca, ws,
+    return ew::tonemap_reinhard_tail(image, out, p.H, p.W, work_dtype, out_dtype, gamma, intensity, p.la, p.ca, ws,
                                      which, bounds, s);
   for (int k = 1; k <= 3; ++k) {
     if (int rc = tm.begin(k)) return rc;
-    if (int rc = ew::tonemap_reinhard_tail(p.dst, p.dst, p.H, p.W, work_dtype, work_dtype, gamma, intensity, p.la,
+    if (int rc = ew::tonemap_reinhard_tail(image, out, p.H, p.W, work_dtype, out_dtype, gamma, intensity, p.la,
                                            p.ca, ws, k, bounds, s))
       return rc;
     if (int rc = tm.end(k)) return rc;
@@ -246,48 +250,52 @@ static int pipeline_params(tile::Params& p, int H, int W, int ids_format, int pa
   return 0;
 }
 
-extern "C" int mi_isp_pipeline12_reinhard(const uint8_t* packed, void* out, int H, int W, int ids_format,
-                                          int pattern, const float* ccm9, int work_dtype, int out_dtype,
-                                          float gamma, float intensity, float light_adapt, float color_adapt,
-                                          void* ws, void* stream) {
-  MI_REQUIRE(out && ws, "pipeline12_reinhard: null pointer");
+// One frame: the cached variant when there is a place for the work-dtype image (the output itself when it has the
+// work dtype, else `work_image`), the recompute variant otherwise.
+static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, int H, int W, int ids_format,
+                            int pattern, const float* ccm9, int work_dtype, int out_dtype, float gamma,
+                            float intensity, float light_adapt, float color_adapt, float* ws, hipStream_t s,
+                            const char* who) {
   tile::Params p = {};
   if (int rc = pipeline_params(p, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma, light_adapt,
                                color_adapt))
     return rc;
-  if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, "pipeline12_reinhard")) return rc;
+  if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, who)) return rc;
+  static const bool no_cached = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
+  void* image = work_dtype == out_dtype ? out : work_image;
+  if (!no_cached && image && vec_store_ok(image, W, work_dtype))
+    return pipeline_frame_cached(p, pattern, work_dtype, gamma, intensity, ws, -1, s, image, out, out_dtype);
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
-  if (use_cached(p, work_dtype, out_dtype))
-    return pipeline_frame_cached(p, pattern, work_dtype, gamma, intensity, static_cast<float*>(ws), -1, (hipStream_t)stream);
-  return pipeline_frame(p, pattern, work_dtype, intensity, static_cast<float*>(ws), (hipStream_t)stream);
+  return pipeline_frame(p, pattern, work_dtype, intensity, ws, s);
 }
 
-extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, void* const* out, int n_frames, int H,
-                                                int W, int ids_format, int pattern, const float* ccm9,
-                                                int work_dtype, int out_dtype, float gamma, float intensity,
-                                                float light_adapt, float color_adapt, void* ws,
-                                                void* const* streams, int n_streams) {
+extern "C" int mi_isp_pipeline12_reinhard(const uint8_t* packed, void* out, void* work_image, int H, int W,
+                                          int ids_format, int pattern, const float* ccm9, int work_dtype,
+                                          int out_dtype, float gamma, float intensity, float light_adapt,
+                                          float color_adapt, void* ws, void* stream) {
+  MI_REQUIRE(out && ws, "pipeline12_reinhard: null pointer");
+  return pipeline12_frame(packed, out, work_image, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma,
+                          intensity, light_adapt, color_adapt, static_cast<float*>(ws), (hipStream_t)stream,
+                          "pipeline12_reinhard");
+}
+
+extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, void* const* out,
+                                                void* const* work_images, int n_frames, int H, int W,
+                                                int ids_format, int pattern, const float* ccm9, int work_dtype,
+                                                int out_dtype, float gamma, float intensity, float light_adapt,
+                                                float color_adapt, void* ws, void* const* streams, int n_streams) {
   MI_REQUIRE(packed && out && ws, "pipeline12_reinhard_batch: null pointer");
   MI_REQUIRE(n_frames >= 0, "pipeline12_reinhard_batch: negative frame count");
   MI_REQUIRE(n_streams >= 1 && streams, "pipeline12_reinhard_batch: need at least one stream");
-  tile::Params base = {};
-  if (int rc = pipeline_params(base, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma, light_adapt,
-                               color_adapt))
-    return rc;
   const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
   for (int i = 0; i < n_frames; ++i) {
     MI_REQUIRE(out[i], "pipeline12_reinhard_batch: output %d is null", i);
-    tile::Params p = base;
-    if (int rc = packed_params(p, packed[i], H, W, 12, ids_format, work_dtype, "pipeline12_reinhard_batch")) return rc;
-    p.dst = out[i];
-    p.vec_store = vec_store_ok(out[i], W, out_dtype);
     float* wsi = static_cast<float*>(ws) + (size_t)i * ws_floats;
-    hipStream_t si = (hipStream_t)streams[i % n_streams];
-    const int rc = use_cached(p, work_dtype, out_dtype)
-                       ? pipeline_frame_cached(p, pattern, work_dtype, gamma, intensity, wsi, -1, si)
-                       : pipeline_frame(p, pattern, work_dtype, intensity, wsi, si);
-    if (rc) return rc;
+    if (int rc = pipeline12_frame(packed[i], out[i], work_images ? work_images[i] : nullptr, H, W, ids_format, pattern,
+                                  ccm9, work_dtype, out_dtype, gamma, intensity, light_adapt, color_adapt, wsi,
+                                  (hipStream_t)streams[i % n_streams], "pipeline12_reinhard_batch"))
+      return rc;
   }
   return 0;
 }
@@ -308,7 +316,7 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
   p.vec_store = vec_store_ok(out, W, out_dtype);
   float* fp = static_cast<float*>(ws);
   if (use_cached(p, work_dtype, out_dtype) && debug_skip == 0)
-    return pipeline_frame_cached(p, pattern, work_dtype, gamma, 1.0f, fp, pass, (hipStream_t)stream);
+    return pipeline_frame_cached(p, pattern, work_dtype, gamma, 1.0f, fp, pass, (hipStream_t)stream, out, out, out_dtype);
   p.fp = fp; p.partials = fp + FP_COUNT; p.part_stride = mi_partial_cap(H, W);
   p.debug_skip = debug_skip & 63;
   static const int epi[4] = {tile::EPI_MINMAX, tile::EPI_STATS, tile::EPI_RH_MINMAX, tile::EPI_RH_STORE};

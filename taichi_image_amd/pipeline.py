@@ -34,8 +34,12 @@ def pipeline12_reinhard(packed, pattern=BayerPattern.RGGB, ids_format=False, cor
     if out is None:
         out = torch.empty((H, W, 3), dtype=odt.torch, device=packed.device)
     ws = _native.workspace(H, W, packed.device)
+    # an output dtype other than the work dtype: scratch for the work-dtype image between the passes (the
+    # caching allocator makes this cheap; without it the library re-derives the image in every pass)
+    work_image = None if odt.code == work.code else torch.empty((H, W, 3), dtype=work.torch, device=packed.device)
     _native.check(_native.lib().mi_isp_pipeline12_reinhard(
-        packed.data_ptr(), out.data_ptr(), H, W, int(bool(ids_format)), pattern.value, _native.ccm_arg(correct_colors),
+        packed.data_ptr(), out.data_ptr(), None if work_image is None else work_image.data_ptr(),
+        H, W, int(bool(ids_format)), pattern.value, _native.ccm_arg(correct_colors),
         work.code, odt.code, float(gamma), float(intensity), float(light_adapt), float(color_adapt), ws.data_ptr(),
         _native.stream_ptr(packed.device)))
     return out
@@ -61,6 +65,10 @@ class BatchPipeline:
         self.ws = torch.zeros(ws_bytes * n_frames, dtype=torch.uint8, device=device)
         self.outputs = [torch.empty((H, W, 3), dtype=self.odt.torch, device=device) for _ in range(n_frames)]
         self.out_ptrs = _native.ptr_array(self.outputs)
+        # scratch for the work-dtype image of every frame when the outputs have another dtype
+        self.work_images = None if self.odt.code == self.work.code else [
+            torch.empty((H, W, 3), dtype=self.work.torch, device=device) for _ in range(n_frames)]
+        self.work_ptrs = None if self.work_images is None else _native.ptr_array(self.work_images)
         # use_graph: the step (fork to the worker streams, 4 launches per frame, join) is captured once
         # into a HIP graph and replayed while the input tensors keep their addresses (a ring of
         # upload buffers does); replay removes the launch gaps between the dependent kernels
@@ -103,7 +111,7 @@ class BatchPipeline:
         in_ptrs = _native.ptr_array(frames)
         g, i, la, ca = self.params
         _native.check(_native.lib().mi_isp_pipeline12_reinhard_batch(
-            in_ptrs, self.out_ptrs, self.n_frames, self.H, self.W, self.ids, self.pattern.value, self.ccm,
+            in_ptrs, self.out_ptrs, self.work_ptrs, self.n_frames, self.H, self.W, self.ids, self.pattern.value, self.ccm,
             self.work.code, self.odt.code, g, i, la, ca, self.ws.data_ptr(), self.stream_ptrs, len(self.streams)))
         for s in self.streams:
             cur.wait_stream(s)

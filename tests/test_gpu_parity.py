@@ -286,6 +286,23 @@ def test_pipeline12_reinhard(ti, rng, dev, p, ids, work, dout, shape):
     assert_close(got, ref, f"pipeline12 {shape} p{p} {work}->{dout}")
 
 
+def test_pipeline12_without_work_image_recomputes(ti, rng, dev):
+    """The C entry point without scratch for the work-dtype image (work_image_dev == NULL) and an output dtype
+    other than the work dtype: every pass re-derives the demosaic from the packed frame (the minimal-traffic
+    variant) - same results as the oracle."""
+    from taichi_image_amd import _native
+    H, W = 70, 200
+    packed = natural_packed12(rng, H, W)
+    pk = torch.from_numpy(packed).to(dev)
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    ws = _native.workspace(H, W, dev)
+    _native.check(_native.lib().mi_isp_pipeline12_reinhard(
+        pk.data_ptr(), out.data_ptr(), None, H, W, 0, 0, None, ti.types.f16.code, ti.types.u8.code, 0.8, 1.0, 1.0, 0.0,
+        ws.data_ptr(), _native.stream_ptr(dev)))
+    assert_close(out.cpu().numpy(), O.pipeline12_reinhard(packed, 0, False, None, "f16", "u8", gamma=0.8),
+                 "pipeline12 recompute variant")
+
+
 def test_pipeline12_params_and_ccm(ti, rng, dev):
     from taichi_image_amd.pipeline import pipeline12_reinhard
     packed = natural_packed12(rng, 96, 160)
