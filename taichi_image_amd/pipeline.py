@@ -51,7 +51,7 @@ class BatchPipeline:
     Owns `n_streams` streams, the per-frame workspaces and the output tensors so that a step is
     one C call issuing 4 launches per frame (7 on the recompute variant) with no allocation on the way."""
 
-    def __init__(self, n_frames, H, W, device, n_streams=4, pattern=BayerPattern.RGGB, ids_format=False,
+    def __init__(self, n_frames, H, W, device, n_streams=2, pattern=BayerPattern.RGGB, ids_format=False,
                  correct_colors=None, work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0,
                  light_adapt=1.0, color_adapt=0.0, use_graph=False):
         self.n_frames, self.H, self.W, self.device = n_frames, H, W, device
