@@ -479,6 +479,7 @@ struct PassArgs {
   // ISP Reinhard (batched): pass 1 derives its scalars from the metering state in its prologue instead of
   // a 1-thread prep launch, pass 2 folds its image's partial maxima instead of a maxout launch
   const float* isp_state9;  // PM_ISP_RH_P1: camera_isp.py:186-195 evaluated per block (NULL: read fp)
+  int no_nan;               // the source image holds no NaN (written by the tile kernel's clamping store)
   int pull_maxout_n;        // PM_ISP_RH_P2: partial maxima per image at partials[part_stride + y * n + i] (0: read maxouts)
 };
 
@@ -654,7 +655,8 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   // One group = 8 pixels = 24 elements.  FULL: the wave's 64 groups are whole, aligned and
   // contiguous, no orientation transform -> wave-contiguous IO through LDS and straight-line code
   // without per-pixel tests.  CA0: color_adapt == 0 (one pow/px).
-  auto group = [&](auto full_c, auto ca0_c, int64_t g, Raw24<TI>& raw) {
+  auto group = [&](auto full_c, auto ca0_c, auto unit_c, int64_t g, Raw24<TI>& raw) {
+    constexpr bool UNIT = decltype(unit_c)::value;       // bounds exactly (0, 1): norm01 is the identity
     constexpr bool FULL = decltype(full_c)::value;
     constexpr bool CA0 = decltype(ca0_c)::value;
     const int64_t px0 = g * 8;
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
       } else {
         float t[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) t[ch] = norm01(x[ch], lo, inv);
+        for (int ch = 0; ch < 3; ++ch) t[ch] = UNIT ? x[ch] : norm01(x[ch], lo, inv);
         if (MODE == PM_STATS) {
           if (live) st.add(t[0], t[1], t[2]);
         } else {
@@ -771,15 +773,21 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
     }
   };
 
+  // (only for images the tile kernel wrote - a.no_nan: its clamp has already mapped NaN to 0, which norm01 would do here)
+  const bool unit_bounds = (MODE == PM_STATS || MODE == PM_RH_MINMAX || MODE == PM_RH_STORE) && a.no_nan && lo == 0.f && inv == 1.f;
   if (rk.ca == 0.f) {
     for (int64_t g = tid; g < n_full; g += PREFETCH * stride) {
 #pragma unroll
       for (int d = 0; d < PREFETCH; ++d)
-        if (g + d * stride < n_full) group(std::true_type{}, std::true_type{}, g + d * stride, raws[d]);
+        if (g + d * stride < n_full) {
+          // image bounds exactly (0, 1) - every frame with a clipped pixel at both ends: clamp((x - 0) * 1) == x
+          if (unit_bounds) group(std::true_type{}, std::true_type{}, std::true_type{}, g + d * stride, raws[d]);
+          else group(std::true_type{}, std::true_type{}, std::false_type{}, g + d * stride, raws[d]);
+        }
     }
-    for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::true_type{}, g, raws[0]);
+    for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::true_type{}, std::false_type{}, g, raws[0]);
   } else {
-    for (int64_t g = tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, g, raws[0]);
+    for (int64_t g = tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, std::false_type{}, g, raws[0]);
   }
 
   if constexpr (PULL_FIN >= 0) {
@@ -1015,6 +1023,7 @@ int tonemap_reinhard_tail(const void* src, void* dst, int H, int W, int in_dtype
   a.gamma_inv = 1.0f / gamma; a.la = la; a.ca = ca;
   a.out_scale = mi_scale_factor(out_dtype); a.transform = MI_T_NONE; a.H = H; a.W = W;
   a.pull_npx = (float)a.n_px; a.pull_intensity = intensity;
+  a.no_nan = bounds.bounds_post > 0;               // the fused pipeline's image (clamped by the tile kernel)
   const int nb = pass_blocks(a.n_px, cap), nbr = pass_blocks(a.n_px, cap, true);
   // measurement aid: MI_ISP_PULL_DEBUG=0 runs single passes (which > 0) on the scalars a full run left
   // in FrameParams, without the pulled finalize
