@@ -116,6 +116,14 @@ int mi_isp_metering_sums(const void* const* images_host, int n_images, int H, in
 int mi_isp_reinhard(void* image_dev, uint8_t* out_dev, int H, int W, int dtype,
                     const float* state9_dev, float gamma, float intensity, float light_adapt,
                     float color_adapt, int transform, void* ws_dev, void* stream);
+/* tonemap_reinhard of a list of images straight to planar YUV 4:2:0 (u8, layout of mi_isp_rgb_to_yuv420): the
+ * second Reinhard pass (camera_isp.py:215-218) fused with color/yuv_420.py:39-66; equals
+ * mi_isp_rgb_to_yuv420(mi_isp_reinhard_batch(...)) without writing and re-reading the u8 RGB images.
+ * Like the reference's pass 1 it overwrites the input images.  H even, W % 16 == 0, no orientation transform. */
+int mi_isp_reinhard_batch_yuv420(void* const* images_host, uint8_t* const* yuv_outs_host, int n, int H, int W,
+                                 int dtype, const float* state9_dev, float gamma, float intensity,
+                                 float light_adapt, float color_adapt, void* ws_dev, void* stream);
+
 /* The per-image loop of ISP.tonemap_reinhard / tonemap_linear (camera_isp.py:399-403,409-413) in
  * one call: n images of the same shape, 4 (Reinhard) or 2 (linear) launches in total instead of per
  * image.  images_host / outs_host: host arrays of device pointers. */

@@ -299,6 +299,31 @@ def camera_isp(name: str, dtype=types.f32):
                 interpolate.transform_code(self.transform), ws.data_ptr(), _native.stream_ptr(self.device)))
             return outputs
 
+        def tonemap_reinhard_yuv420(self, images: List[torch.Tensor],
+                                    gamma: float = 1.0, intensity: float = 1.0, light_adapt: float = 1.0,
+                                    color_adapt: float = 0.0):
+            """Extension (not in the reference): `[color.rgb_yuv420_image(o) for o in tonemap_reinhard(images, ...)]`
+            - planar YUV 4:2:0 u8 `(H * 3 / 2, W)` per image for video encoders - with the conversion
+            (color/yuv_420.py:39-66) fused into the second Reinhard pass when no orientation transform is set
+            and W % 16 == 0: the u8 RGB images are never written.  Same side effects as tonemap_reinhard."""
+            from . import color
+            _typecheck("images", images, list)
+            H, W = images[0].shape[:2]
+            if self.transform != interpolate.ImageTransform.none or H % 2 or W % 16:
+                return [color.rgb_yuv420_image(o) for o in self.tonemap_reinhard(images, gamma, intensity,
+                                                                                  light_adapt, color_adapt)]
+            for n, v in (("gamma", gamma), ("intensity", intensity), ("light_adapt", light_adapt),
+                         ("color_adapt", color_adapt)):
+                _typecheck(n, v, float)
+            self.update_metering(images)
+            outputs = [torch.empty((H * 3 // 2, W), dtype=torch.uint8, device=self.device) for _ in images]
+            ws = _native.workspace(H, W, self.device)
+            _native.check(_native.lib().mi_isp_reinhard_batch_yuv420(
+                _native.ptr_array(images), _native.ptr_array(outputs), len(images), H, W, dtype.code,
+                self.metrics.data_ptr(), float(gamma), float(intensity), float(light_adapt), float(color_adapt),
+                ws.data_ptr(), _native.stream_ptr(self.device)))
+            return outputs
+
         def tonemap_linear(self, images: List[torch.Tensor], gamma: float = 1.0):
             """camera_isp.py:405-413."""
             _typecheck("images", images, list)

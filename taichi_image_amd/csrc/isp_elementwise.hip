@@ -808,6 +808,82 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
 }
 
 // ---------------------------------------------------------------------------------------------
+// ISP Reinhard pass 2 with the u8 result converted to planar YUV 4:2:0 on the way (the step after
+// the path for video encoders): per lane 2 rows x 8 pixels.  Exactly rgb_yuv420(u8 image of pass 2): the u8
+// values are formed (camera_isp.py:215-218), then fed to the conversion of color/yuv_420.py:39-66 - the u8 RGB
+// image itself (3 B/px written, 3 B/px read back) is never stored.  grid = (blocks, n_images).
+// ---------------------------------------------------------------------------------------------
+template <class TI>
+__global__ __launch_bounds__(EW_THREADS) void isp_p2_yuv420_kernel(const ew::PtrList srcs, const ew::PtrList dsts, int H, int W,
+                                                                   float gamma_inv, const float* __restrict__ pmax, int nb) {
+#pragma clang fp contract(fast)
+  __shared__ float sh[EW_THREADS / 64];
+  const TI* src = static_cast<const TI*>(srcs.p[blockIdx.y]);
+  uint8_t* yuv = static_cast<uint8_t*>(const_cast<void*>(dsts.p[blockIdx.y]));
+  // max_out of this image (camera_isp.py:190,213) from the partial maxima of pass 1
+  float m = -__builtin_inff();
+  for (int i = threadIdx.x; i < nb; i += EW_THREADS) m = fmaxf(m, pmax[(size_t)blockIdx.y * nb + i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = sh[0];
+#pragma unroll
+  for (int w = 1; w < EW_THREADS / 64; ++w) m = fmaxf(m, sh[w]);
+  const float maxout_inv = 1.0f / fmaxf(1e-6f, m);
+
+  const int hb = H / 2, wb = W / 2, groups = W / 8;
+  uint8_t* yp = yuv;
+  uint8_t* plane0 = yuv + (size_t)H * W;
+  uint8_t* plane1 = plane0 + (size_t)hb * wb;
+  const int64_t n = (int64_t)hb * groups, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int br = (int)(i / groups), g = (int)(i - (int64_t)br * groups);
+    float a[2][24];
+    load24<TI>(src + ((size_t)(2 * br) * W + 8 * g) * 3, a[0], 8, true);
+    load24<TI>(src + ((size_t)(2 * br + 1) * W + 8 * g) * 3, a[1], 8, true);
+    float u[2][8], v[2][8];
+    uint8_t yo[2][8];
+#pragma unroll
+    for (int dr = 0; dr < 2; ++dr) {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) a[dr][j] *= maxout_inv;
+      if (gamma_inv != 1.f) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 24; ++j) a[dr][j] = hw_pow(a[dr][j], gamma_inv);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)                 // the u8 pixel of pass 2, back in [0, 1] (yuv_420.py:52)
+          rgb[ch] = div_scale<uint8_t>((float)cast_out<uint8_t>(a[dr][3 * k + ch] * 255.f));
+        float t[3];
+        {
+#pragma clang fp contract(off)
+          ycrcb_from_rgb(rgb[0], rgb[1], rgb[2], t);
+        }
+        yo[dr][k] = cast_out<uint8_t>(fminf(1.0f, t[0]) * 255.f);
+        u[dr][k] = t[1]; v[dr][k] = t[2];
+      }
+    }
+    uint8_t uo[4], vo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma clang fp contract(off)
+      const float su = (((0.f + u[0][2 * c]) + u[0][2 * c + 1]) + u[1][2 * c]) + u[1][2 * c + 1];
+      const float sv = (((0.f + v[0][2 * c]) + v[0][2 * c + 1]) + v[1][2 * c]) + v[1][2 * c + 1];
+      uo[c] = cast_out<uint8_t>(fminf(1.0f, su / 4.0f) * 255.f);
+      vo[c] = cast_out<uint8_t>(fminf(1.0f, sv / 4.0f) * 255.f);
+    }
+    store_vec<uint8_t, 8>(yp + (size_t)(2 * br) * W + 8 * g, yo[0]);
+    store_vec<uint8_t, 8>(yp + (size_t)(2 * br + 1) * W + 8 * g, yo[1]);
+    store_vec<uint8_t, 4>(plane1 + (size_t)br * wb + 4 * g, uo);
+    store_vec<uint8_t, 4>(plane0 + (size_t)br * wb + 4 * g, vo);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K8 metering on the stride-subsampled images (camera_isp.py:142-175), two data passes.
 // grid = (blocks_per_image, n_images); partial index = blockIdx.y * gridDim.x + blockIdx.x + base
 // ---------------------------------------------------------------------------------------------
@@ -1396,6 +1472,52 @@ extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, 
     if (int rc = launch_pass(PM_ISP_RH_P1, dtype, MI_U8, a, nb, s, m)) return rc;
     a.pull_maxout_n = nb;                                    // max_out per image folded in pass 2's prologue
     if (int rc = launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s, m)) return rc;
+  }
+  return 0;
+}
+
+// tonemap_reinhard of a list of images straight to planar YUV 4:2:0 (u8): pass 1 as in mi_isp_reinhard_batch (the images
+// are overwritten with p, camera_isp.py:211), pass 2 fused with the conversion.  No orientation transform.
+extern "C" int mi_isp_reinhard_batch_yuv420(void* const* images, uint8_t* const* yuv_outs, int n, int H, int W, int dtype,
+                                            const float* state9, float gamma, float intensity, float light_adapt,
+                                            float color_adapt, void* ws, void* stream) {
+  MI_REQUIRE(images && yuv_outs && state9 && ws, "reinhard_batch_yuv420: null pointer");
+  MI_REQUIRE(n >= 0, "reinhard_batch_yuv420: negative image count");
+  MI_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 16 == 0, "reinhard_batch_yuv420: H must be even and W a multiple of 16, got %dx%d", H, W);
+  MI_REQUIRE(dtype == MI_F16 || dtype == MI_F32, "reinhard_batch_yuv420: image must be f16 or f32");
+  MI_REQUIRE(gamma > 0.f, "reinhard_batch_yuv420: gamma must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  float* fp = static_cast<float*>(ws);
+  float* partials = fp + FP_COUNT;
+  const int cap = mi_partial_cap(H, W);
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int m = n - i0 < 64 ? n - i0 : 64;
+    PassArgs a = {};
+    a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
+    a.vec_in = 1; a.vec_out = 1;
+    a.isp_state9 = state9; a.pull_intensity = intensity;
+    ew::PtrList outs = {};
+    for (int i = 0; i < m; ++i) {
+      MI_REQUIRE(images[i0 + i] && yuv_outs[i0 + i], "reinhard_batch_yuv420: image %d is null", i0 + i);
+      MI_REQUIRE(vec_ok(images[i0 + i], dtype) && mi_aligned(yuv_outs[i0 + i], 16), "reinhard_batch_yuv420: buffers must be 16-byte aligned");
+      a.srcs.p[i] = images[i0 + i]; a.dsts.p[i] = yuv_outs[i0 + i];
+      outs.p[i] = yuv_outs[i0 + i];
+    }
+    a.batched = 1;
+    a.gamma_inv = (float)(1.0 / (double)gamma); a.la = light_adapt; a.ca = color_adapt; a.out_scale = 255.f;
+    a.transform = MI_T_NONE; a.H = H; a.W = W;
+    const int nb = pass_blocks(a.n_px, cap / m > 0 ? cap / m : 1);
+    if (int rc = launch_pass(PM_ISP_RH_P1, dtype, MI_U8, a, nb, s, m)) return rc;
+    const int64_t lanes = (int64_t)(H / 2) * (W / 8);
+    int blocks = (int)((lanes + EW_THREADS - 1) / EW_THREADS);
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == MI_F16)
+      hipLaunchKernelGGL((isp_p2_yuv420_kernel<half_t>), dim3(blocks, m), dim3(EW_THREADS), 0, s, a.srcs, outs, H, W, a.gamma_inv,
+                         partials + cap, nb);
+    else
+      hipLaunchKernelGGL((isp_p2_yuv420_kernel<float>), dim3(blocks, m), dim3(EW_THREADS), 0, s, a.srcs, outs, H, W, a.gamma_inv,
+                         partials + cap, nb);
+    MI_LAUNCH_CHECK();
   }
   return 0;
 }

@@ -686,3 +686,28 @@ def test_isp_sharded_metering_path_equals_fused(ti, rng, dev):
         assert_close(b.metrics.cpu().numpy(), a.metrics.cpu().numpy(), f"metering state, call {step}", rel=1e-5)
         for x, y in zip(oa, ob):
             assert_close(y.cpu().numpy(), x.cpu().numpy(), f"u8 output, call {step}")
+
+
+@pytest.mark.parametrize("cam", ["Camera16", "Camera32"])
+def test_isp_tonemap_reinhard_yuv420_fused(ti, rng, dev, cam):
+    """The fused second pass + YUV 4:2:0 conversion equals converting the u8 outputs of tonemap_reinhard, bit
+    for bit, over two calls (rolling metering), including the in-place side effect on the inputs; and the
+    fallback (orientation transform set) gives the conversion of the transformed outputs."""
+    from taichi_image_amd import color
+    H, W = 96, 160
+    frames = [torch.from_numpy(natural_packed12(rng, H, W)).to(dev) for _ in range(3)]
+    a = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.2, device=dev)
+    b = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.2, device=dev)
+    for call in range(2):
+        ia = [a.load_packed12(f) for f in frames]
+        ib = [b.load_packed12(f) for f in frames]
+        want = [color.rgb_yuv420_image(o) for o in a.tonemap_reinhard(ia, gamma=0.6, intensity=1.2)]
+        got = b.tonemap_reinhard_yuv420(ib, gamma=0.6, intensity=1.2)
+        for g, w_, x, y in zip(got, want, ia, ib):
+            assert g.shape == (H * 3 // 2, W) and g.dtype == torch.uint8
+            assert torch.equal(g, w_), f"call {call}"
+            assert torch.equal(x, y), "inputs overwritten with the same p"
+    c = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, transform=ti.ImageTransform.flip_horiz)
+    d = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, transform=ti.ImageTransform.flip_horiz)
+    ic, id_ = [c.load_packed12(frames[0])], [d.load_packed12(frames[0])]
+    assert torch.equal(d.tonemap_reinhard_yuv420(id_, gamma=0.6)[0], color.rgb_yuv420_image(c.tonemap_reinhard(ic, gamma=0.6)[0]))
