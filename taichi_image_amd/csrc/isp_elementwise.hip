@@ -1315,9 +1315,13 @@ static int metering_pass(int phase, const void* const* images, int n_images, int
                          int dtype, const float* bounds, float* partials, int cap, int* nblocks_out,
                          hipStream_t s) {
   const int hs = (H + stride - 1) / stride, ws = (W + stride - 1) / stride;
+  // the strided gather is latency-bound (one 64-byte line per pixel): few pixels per thread, as many blocks per
+  // image as the partial rows allow (16 blocks per image measured 44 us for six 4K images, 192: see DESIGN.md 7)
   int bpi = (hs * ws + EW_THREADS * 4 - 1) / (EW_THREADS * 4);
+  const int room = cap / (n_images > 0 ? n_images : 1);
+  if (bpi > room) bpi = room;
+  if (bpi > 256) bpi = 256;
   if (bpi < 1) bpi = 1;
-  if (bpi > 16) bpi = 16;
   MI_REQUIRE((int64_t)bpi * n_images <= cap, "metering: too many images (%d) for the workspace", n_images);
   int base = 0;
   for (int i0 = 0; i0 < n_images; i0 += 64) {
