@@ -775,7 +775,9 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
 
   // (only for images the tile kernel wrote - a.no_nan: its clamp has already mapped NaN to 0, which norm01 would do here)
   const bool unit_bounds = (MODE == PM_STATS || MODE == PM_RH_MINMAX || MODE == PM_RH_STORE) && a.no_nan && lo == 0.f && inv == 1.f;
-  if (rk.ca == 0.f) {
+  // the colour-adapt variant (three pows per pixel) only exists for the modes that evaluate reinhard_px
+  constexpr bool HAS_REINHARD = MODE == PM_RH_MINMAX || MODE == PM_RH_STORE || MODE == PM_ISP_RH_P1;
+  if (!HAS_REINHARD || rk.ca == 0.f) {
     for (int64_t g = tid; g < n_full; g += PREFETCH * stride) {
 #pragma unroll
       for (int d = 0; d < PREFETCH; ++d)
