@@ -789,7 +789,13 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
     }
     for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::true_type{}, std::false_type{}, g, raws[0]);
   } else {
-    for (int64_t g = tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, std::false_type{}, g, raws[0]);
+    // colour adaptation (three pows per pixel): whole groups keep the wave-cooperative IO
+    for (int64_t g = tid; g < n_full; g += PREFETCH * stride) {
+#pragma unroll
+      for (int d = 0; d < PREFETCH; ++d)
+        if (g + d * stride < n_full) group(std::true_type{}, std::false_type{}, std::false_type{}, g + d * stride, raws[d]);
+    }
+    for (int64_t g = n_full + tid; g < n_groups; g += stride) group(std::false_type{}, std::false_type{}, std::false_type{}, g, raws[0]);
   }
 
   if constexpr (PULL_FIN >= 0) {
