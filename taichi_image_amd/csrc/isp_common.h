@@ -191,6 +191,18 @@ MI_DEV void wave_store24(T* gptr, int lane, void* lbuf_, const T (&t)[24]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) lbuf[lane * N + j] = mine[j];
   __builtin_amdgcn_wave_barrier();
+  if constexpr (sizeof(T) == 1) {
+    // 1-byte elements: the wave's 1536 bytes leave as 96 16-byte units (lanes 0..63, then 0..31) instead of 192
+    // 8-byte ones when the destination allows it (wave-uniform test)
+    if ((reinterpret_cast<uintptr_t>(gptr) & 15) == 0) {
+      const uint4* l4 = reinterpret_cast<const uint4*>(lbuf_);
+      uint4* g4 = reinterpret_cast<uint4*>(gptr);
+      g4[lane] = l4[lane];
+      if (lane < 32) g4[64 + lane] = l4[64 + lane];
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
+  }
   U* g = reinterpret_cast<U*>(gptr);
 #pragma unroll
   for (int j = 0; j < N; ++j) g[j * 64 + lane] = lbuf[j * 64 + lane];
