@@ -7,8 +7,9 @@ PARITY STATUS: *parity unpinned* by the reference for everything except the pack
 taichi_image/test/packed.py:6-15).  The reference cannot be executed here (its
 ``taichi`` dependency is not installed and cannot be installed), and it ships no golden
 vectors.  This restatement is therefore pinned by (a) that round trip, (b) hand-derived
-known-answer vectors from the reference's bit formulas (tests/golden/kat.json) and
-(c) algebraic properties (constant-CFA invariance, channel weight sums == 16, ...).
+known-answer vectors from the reference's bit formulas (tests/golden/kat.json),
+(c) algebraic properties (constant-CFA invariance, channel weight sums == 16, ...) and
+(d) the published Malvar-He-Cutler (2004) filters for the demosaic stage (tests/test_oracle.py).
 
 Every function cites the reference lines it restates (paths relative to
 /root/reference/taichi_image/).  Arithmetic is carried out in float32 in the same

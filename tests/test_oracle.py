@@ -203,3 +203,34 @@ def test_scaled_division_trick():
         q2 = (q.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(f32)
         want = x.astype(f32) / f32(d)
         assert (q != want).any() and np.array_equal(q2, want)
+
+
+def test_demosaic_equals_published_malvar_he_cutler(rng):
+    """An independent pin of the weight tables: the reference's kernels are Malvar-He-Cutler 2004 ("High-quality
+    linear interpolation for demosaicing of Bayer-patterned color images", ICASSP 2004; the reference's own
+    test/compare_bayer.py compares against that algorithm).  The paper's four 5x5 filters (coefficients / 8),
+    applied with plain correlations, reproduce the oracle's interior for all four CFA patterns."""
+    from scipy.ndimage import correlate
+    g_at_rb = np.array([[0, 0, -1, 0, 0], [0, 0, 2, 0, 0], [-1, 2, 4, 2, -1], [0, 0, 2, 0, 0], [0, 0, -1, 0, 0]]) / 8.0
+    # R at a green site whose row holds R (horizontal R neighbours); its transpose serves the other green site
+    rb_at_g_row = np.array([[0, 0, 0.5, 0, 0], [0, -1, 0, -1, 0], [-1, 4, 5, 4, -1], [0, -1, 0, -1, 0], [0, 0, 0.5, 0, 0]]) / 8.0
+    rb_at_g_col = rb_at_g_row.T
+    rb_at_br = np.array([[0, 0, -1.5, 0, 0], [0, 2, 0, 2, 0], [-1.5, 0, 6, 0, -1.5], [0, 2, 0, 2, 0], [0, 0, -1.5, 0, 0]]) / 8.0
+    H, W = 24, 32
+    cfa = rng.random((H, W)).astype(np.float64)
+    conv = {k: correlate(cfa, f, mode="constant") for k, f in
+            (("g", g_at_rb), ("row", rb_at_g_row), ("col", rb_at_g_col), ("diag", rb_at_br))}
+    rr, cc = np.mgrid[0:H, 0:W]
+    # (row parity, col parity) of the red site per pattern (bayer.py:85-90 pixel orders)
+    red_site = {O.RGGB: (0, 0), O.GRBG: (0, 1), O.GBRG: (1, 0), O.BGGR: (1, 1)}
+    for pattern, (pr, pc) in red_site.items():
+        is_r = ((rr % 2) == pr) & ((cc % 2) == pc)
+        is_b = ((rr % 2) != pr) & ((cc % 2) != pc)
+        g_in_r_row = ((rr % 2) == pr) & ((cc % 2) != pc)          # green with red left / right
+        g_in_b_row = ((rr % 2) != pr) & ((cc % 2) == pc)          # green with red above / below
+        R = np.where(is_r, cfa, np.where(g_in_r_row, conv["row"], np.where(g_in_b_row, conv["col"], conv["diag"])))
+        G = np.where(is_r | is_b, conv["g"], cfa)
+        B = np.where(is_b, cfa, np.where(g_in_b_row, conv["row"], np.where(g_in_r_row, conv["col"], conv["diag"])))
+        want = np.clip(np.stack([R, G, B], -1), 0, 1)
+        got = O.bayer_to_rgb(cfa.astype(np.float32), pattern).astype(np.float64)
+        assert np.abs(got[2:-2, 2:-2] - want[2:-2, 2:-2]).max() < 2e-6, f"pattern {pattern}"
