@@ -72,3 +72,58 @@ def pipeline12_reinhard(packed, pattern=0, ids=False, work="f16", out="f16", gam
                                   ctypes.c_float(intensity), ctypes.c_float(light_adapt), ctypes.c_float(color_adapt),
                                   kind, _p(res))
     return res.view(np.float16) if out == "f16" else res
+
+
+# ---- camera_isp.py stateful path (full-size checks of the ISP metering / Reinhard / linear kernels) ----
+def _as_f32_images(images):
+    ims = [np.ascontiguousarray(im, np.float32) for im in images]
+    ptrs = (ctypes.c_void_p * len(ims))(*[im.ctypes.data for im in ims])
+    return ims, ptrs
+
+
+def metering_images(images, alpha, prev, stride=8):
+    """camera_isp.py:142-175; images: list of (H, W, 3) f16/f32 arrays; prev: f32[9]."""
+    ims, ptrs = _as_f32_images(images)
+    H, W, _ = ims[0].shape
+    prev = np.ascontiguousarray(prev, np.float32)
+    out = np.empty(9, np.float32)
+    lib().orc_metering_images(ptrs, len(ims), H, W, int(stride), ctypes.c_float(alpha), _p(prev), _p(out))
+    return out
+
+
+class IspState:
+    """The rolling state of camera_isp.ISP (camera_isp.py:267,376-385) on the C oracle."""
+
+    def __init__(self, moving_alpha=0.1, stride=8):
+        self.metrics = None
+        self.moving_alpha = moving_alpha
+        self.stride = stride
+
+    def update_metering(self, images):
+        if self.metrics is None:
+            self.metrics = metering_images(images, 0.0, np.zeros(9, np.float32), self.stride)
+        else:
+            self.metrics = metering_images(images, 1.0 - self.moving_alpha, self.metrics, self.stride)
+        return self.metrics
+
+
+def reinhard_isp(image, m, gamma=1.0, intensity=1.0, light_adapt=1.0, color_adapt=0.0):
+    """camera_isp.py:177-218 -> (u8 output, image after the in-place write-back, in the image dtype)."""
+    dt = image.dtype
+    work = np.ascontiguousarray(image, np.float32).copy()
+    H, W, _ = work.shape
+    out = np.empty((H, W, 3), np.uint8)
+    m = np.ascontiguousarray(m, np.float32)
+    lib().orc_reinhard_isp(_p(work), H, W, int(dt == np.float16), _p(m), ctypes.c_float(gamma),
+                           ctypes.c_float(intensity), ctypes.c_float(light_adapt), ctypes.c_float(color_adapt),
+                           _p(out), None)
+    return out, work.astype(dt)
+
+
+def linear_isp(image, m, gamma=1.0):
+    src = np.ascontiguousarray(image, np.float32)
+    H, W, _ = src.shape
+    out = np.empty((H, W, 3), np.uint8)
+    m = np.ascontiguousarray(m, np.float32)
+    lib().orc_linear_isp(_p(src), H, W, _p(m), ctypes.c_float(gamma), _p(out))
+    return out

@@ -264,3 +264,105 @@ void orc_pipeline12_reinhard(const uint8_t* packed, int H, int W, int ids, int p
   free(cfa);
   free(rgb);
 }
+
+/* ==== camera_isp.py: the stateful ISP tonemap (metering state + Reinhard / linear to u8) ==========
+ * Images are f32 arrays holding work-dtype values (f16 values widened exactly, or f32);
+ * `work_f16` says which dtype the reference image has (it decides the rounding of the in-place
+ * write-back of camera_isp.py:211). */
+
+/* util.py:83-84 */
+static inline float lerpf(float t, float a, float b) { return a + t * (b - a); }
+
+/* camera_isp.py:142-175: metering_images over the stride-subsample of n images.
+ * Sums are evaluated in float64 and rounded once (the reference's atomic-add order is not
+ * deterministic); everything else is float32 in the reference's operation order. */
+void orc_metering_images(const float* const* images, int n, int H, int W, int stride, float alpha, const float* prev9,
+                         float* out9) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (int k = 0; k < n; ++k) {
+    const float* im = images[k];
+#pragma omp parallel for reduction(min : lo) reduction(max : hi) schedule(static)
+    for (int r = 0; r < H; r += stride)
+      for (int c = 0; c < W; c += stride)
+        for (int ch = 0; ch < 3; ++ch) {                                       /* :151-154 */
+          const float v = im[((size_t)r * W + c) * 3 + ch];
+          lo = fminf(lo, v);
+          hi = fmaxf(hi, v);
+        }
+  }
+  const float bmin = lerpf(alpha, lo, prev9[0]), bmax = lerpf(alpha, hi, prev9[1]);   /* :156-157 */
+  double slog = 0, sgray = 0, s0 = 0, s1 = 0, s2 = 0;
+  float lmin = INFINITY, lmax = -INFINITY;
+  long cnt = 0;
+  const float den = bmax - bmin + 1e-6f;                                       /* :118 */
+  for (int k = 0; k < n; ++k) {
+    const float* im = images[k];
+#pragma omp parallel for reduction(+ : slog, sgray, s0, s1, s2, cnt) reduction(min : lmin) reduction(max : lmax) schedule(static)
+    for (int r = 0; r < H; r += stride)
+      for (int c = 0; c < W; c += stride) {
+        const float* p = im + ((size_t)r * W + c) * 3;
+        const float t[3] = {(p[0] - bmin) / den, (p[1] - bmin) / den, (p[2] - bmin) / den};
+        const float g = gray3(t);                                              /* :119 */
+        const float lg = logf(fmaxf(g, 1e-4f));                               /* :120 */
+        if (!isnan(lg)) { lmin = fminf(lmin, lg); lmax = fmaxf(lmax, lg); }   /* :122-123 */
+        slog += lg; sgray += g; s0 += t[0]; s1 += t[1]; s2 += t[2];           /* :125-127 */
+        cnt += 1;
+      }
+  }
+  const float nn = (float)cnt;                                                 /* :164 n = N * H' * W' */
+  const float v[9] = {bmin, bmax, lmin, lmax, (float)slog / nn, (float)sgray / nn,
+                      (float)s0 / nn, (float)s1 / nn, (float)s2 / nn};         /* :131-134 */
+  for (int i = 0; i < 9; ++i) out9[i] = lerpf(alpha, v[i], prev9[i]);          /* :165-166 */
+}
+
+/* camera_isp.py:177-218: reinhard_kernel.  image (f32 holding work-dtype values) is overwritten
+ * with p rounded to the work dtype (:211); out_u8 receives cast(255 * (p/max_out)^(1/gamma)). */
+void orc_reinhard_isp(float* image, int H, int W, int work_f16, const float* m9, float gamma, float intensity,
+                      float la, float ca, uint8_t* out_u8, float* max_out_ret) {
+  const size_t n = (size_t)H * W;
+  const float bmin = m9[0], bmax = m9[1], lmin = m9[2], lmax = m9[3], lmean = m9[4], mean = m9[5];
+  const float key = (lmax - lmean) / (lmax - lmin);                            /* :192 */
+  const float map_key = 0.3f + 0.7f * powf(key, 1.4f);                         /* :193 */
+  float mean3[3];
+  for (int c = 0; c < 3; ++c) mean3[c] = mean + ca * (m9[6 + c] - mean);       /* :195 */
+  const float ei = expf(-intensity);
+  const float range = bmax - bmin;
+  float max_p = -INFINITY;
+#pragma omp parallel for reduction(max : max_p) schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    float* px = image + 3 * i;
+    const float t[3] = {(px[0] - bmin) / range, (px[1] - bmin) / range, (px[2] - bmin) / range};   /* :200 */
+    const float g = gray3(t);
+    for (int c = 0; c < 3; ++c) {
+      const float ac = g + ca * (t[c] - g);                                    /* :204 */
+      const float am = mean3[c] + la * (ac - mean3[c]);                        /* :207 */
+      const float ad = powf(ei * am, map_key);                                 /* :208 */
+      const float p = t[c] * (1.0f / (ad + t[c]));                             /* :210 */
+      if (!isnan(p)) max_p = fmaxf(max_p, p);                                  /* :213 */
+      px[c] = work_f16 ? round_f16(p) : p;                                     /* :211 */
+    }
+  }
+  const float max_out = fmaxf(1e-6f, max_p);                                   /* :190 */
+  const float ginv = 1.0f / gamma;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n * 3; ++i) {
+    float q = 255.f * powf(image[i] / max_out, ginv);                          /* :217-218 */
+    if (isnan(q)) q = 0.f;
+    q = fminf(fmaxf(q, 0.f), 255.f);
+    out_u8[i] = (uint8_t)q;
+  }
+  if (max_out_ret) *max_out_ret = max_out;
+}
+
+/* camera_isp.py:220-227 -> tonemap.py:12-17 with the metering bounds, u8 out */
+void orc_linear_isp(const float* image, int H, int W, const float* m9, float gamma, uint8_t* out_u8) {
+  const size_t n = (size_t)H * W * 3;
+  const float lo = m9[0], inv = 1.0f / (m9[1] - m9[0]), ginv = 1.0f / gamma;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    float x = powf((image[i] - lo) * inv, ginv);
+    x = fminf(fmaxf(x, 0.f), 1.f);
+    if (isnan(x)) x = 0.f;
+    out_u8[i] = (uint8_t)(x * 255.f);
+  }
+}

@@ -48,3 +48,21 @@ def test_pipeline(rng, out, kw):
     work = "f32" if out == "f32" else "f16"
     got = c_oracle.pipeline12_reinhard(packed, work=work, out=out, **kw)
     assert_close(got, O.pipeline12_reinhard(packed, work=work, out=out, **kw), f"C vs NumPy pipeline {out}")
+
+
+@pytest.mark.parametrize("work", ["f16", "f32"])
+def test_isp_stateful_path(rng, work):
+    """camera_isp.py:142-227 in C against the NumPy restatement: the 9-vector over three steps (moving
+    average), the u8 outputs and the in-place write-back of Reinhard, the linear map."""
+    st_c, st_n = c_oracle.IspState(0.3), O.IspState(0.3)
+    for step in range(3):
+        imgs = [O.isp_load_packed12(natural_packed12(rng, 80, 96, dark=0.05 * step), work) for _ in range(3)]
+        mc, mn = st_c.update_metering(imgs), st_n.update_metering(imgs)
+        assert_close(mc, mn, f"metering step {step}", rel=2e-6)
+        for kw in (dict(gamma=0.6), dict(gamma=1.0, intensity=0.7, light_adapt=0.8, color_adapt=0.3)):
+            for im in imgs:
+                u8_c, after_c = c_oracle.reinhard_isp(im, mn, **kw)
+                u8_n, after_n = O.reinhard_isp(im, mn, **kw)
+                assert_close(u8_c, u8_n, "reinhard u8")
+                assert_close(after_c, after_n, "reinhard write-back")
+        assert_close(c_oracle.linear_isp(imgs[0], mn, 0.8), O.linear_isp(imgs[0], mn, 0.8), "linear")

@@ -1,0 +1,145 @@
+"""GPU parity at the BASELINE sizes for the stateful ISP leg (camera_isp.py:142-227,376-413) and the
+general (non-unit bounds) path of the fused config-2 chain.
+
+The small-size tests of test_gpu_parity.py run these kernels with one block per image; here
+`metering_kernel` (up to 256 blocks per image), the batched `rgb_pass_kernel<PM_ISP_RH_P1/P2>`
+(grid.y = image, per-image max_out folding) and the 64-image chunking meet the C oracle
+(oracle/isp_oracle.c, pinned against the NumPy restatement by tests/test_c_oracle.py) with many
+blocks, six images of differing brightness and three consecutive calls (moving average).
+
+The oracle consumes the image the device loader produced (its own parity is bit-exact and tested
+in test_gpu_parity.py), copied to the host BEFORE the tonemap mutates it in place.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, isp_oracle as O
+from tests.util import assert_close, natural_packed12
+from taichi_image_amd.synthetic import mosaic_rggb, pack12, synthetic_scene
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not c_oracle.available(), reason="oracle/liborc_isp.so not built")]
+
+
+@pytest.fixture(scope="module")
+def ti():
+    import taichi_image_amd as t
+    return t
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    """Six 4096x3072 scenes (SURVEY 8(d) generator), kept as f32 CFA in [0, 1]."""
+    return [mosaic_rggb(synthetic_scene(k)) for k in range(6)]
+
+
+def packed_from(cfa, gain=1.0, offset=0.0):
+    """12-bit frame of gain * scene + offset (clipped): frames of differing brightness and bounds."""
+    v12 = np.rint(np.clip(cfa.astype(np.float64) * gain + offset, 0, 1) * 4095).astype(np.uint16)
+    return pack12(v12)
+
+
+# brightness of the six cameras of one call, and the drift from call to call (moving average)
+GAINS = [1.0, 0.55, 0.8, 0.3, 0.95, 0.7]
+OFFSETS = [0.0, 0.02, 0.1, 0.0, 0.04, 0.15]
+
+
+def load_group(isp, scenes, step, dev):
+    imgs = []
+    for k, cfa in enumerate(scenes):
+        p = packed_from(cfa, GAINS[(k + step) % 6] * (1.0 - 0.12 * step), OFFSETS[(k + 2 * step) % 6])
+        imgs.append(isp.load_packed12(torch.from_numpy(p).to(dev)))
+    return imgs
+
+
+@pytest.mark.parametrize("cam,resize_width", [("Camera16", 1920), ("Camera16", 0), ("Camera32", 0)])
+def test_isp_reinhard_full_size_sequence(ti, dev, scenes, cam, resize_width):
+    """Camera16(resize_width=1920) -> 1440x1920 and full-resolution Camera16 / Camera32: six images, three
+    consecutive tonemap_reinhard(gamma=0.6) calls; metrics, u8 outputs and the in-place p against the C oracle."""
+    isp = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.3, resize_width=resize_width, device=dev)
+    st = c_oracle.IspState(0.3)
+    for step in range(3):
+        imgs = load_group(isp, scenes, step, dev)
+        refs = [im.cpu().numpy() for im in imgs]                 # before the in-place write-back
+        assert refs[0].shape == ((1440, 1920, 3) if resize_width else (3072, 4096, 3))
+        outs = isp.tonemap_reinhard(imgs, gamma=0.6)
+        m = st.update_metering(refs)
+        assert_close(isp.metrics.cpu().numpy(), m, f"{cam} metrics step {step}", rel=2e-5)
+        for k, (o, im, r) in enumerate(zip(outs, imgs, refs)):
+            ref_u8, ref_after = c_oracle.reinhard_isp(r, m, gamma=0.6)
+            assert_close(o.cpu().numpy(), ref_u8, f"{cam} u8 step {step} img {k}")
+            assert_close(im.cpu().numpy(), ref_after, f"{cam} in-place p step {step} img {k}")
+        # the six images must not share a max_out: their outputs differ
+        assert len({int(o.float().mean().item() * 1000) for o in outs}) > 1
+
+
+@pytest.mark.parametrize("cam,resize_width", [("Camera16", 1920), ("Camera32", 0)])
+def test_isp_linear_full_size(ti, dev, scenes, cam, resize_width):
+    isp = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.5, resize_width=resize_width, device=dev)
+    st = c_oracle.IspState(0.5)
+    for step in range(2):
+        imgs = load_group(isp, scenes[:4], step, dev)
+        refs = [im.cpu().numpy() for im in imgs]
+        outs = isp.tonemap_linear(imgs, gamma=0.8)
+        m = st.update_metering(refs)
+        assert_close(isp.metrics.cpu().numpy(), m, f"{cam} metrics step {step}", rel=2e-5)
+        for k, (o, r) in enumerate(zip(outs, refs)):
+            assert_close(o.cpu().numpy(), c_oracle.linear_isp(r, m, 0.8), f"{cam} linear step {step} img {k}")
+
+
+def test_isp_reinhard_yuv420_full_size(ti, dev, scenes):
+    """The fused second pass + YUV conversion at 1440x1920, four images of differing brightness, two steps."""
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.4, resize_width=1920, device=dev)
+    st = c_oracle.IspState(0.4)
+    for step in range(2):
+        imgs = load_group(isp, scenes[:4], step, dev)
+        refs = [im.cpu().numpy() for im in imgs]
+        outs = isp.tonemap_reinhard_yuv420(imgs, gamma=0.6)
+        m = st.update_metering(refs)
+        for k, (o, r) in enumerate(zip(outs, refs)):
+            ref_u8, _ = c_oracle.reinhard_isp(r, m, gamma=0.6)
+            got = o.cpu().numpy()
+            want = O.rgb_yuv420(ref_u8)
+            assert got.shape == want.shape
+            # a u8 RGB value one LSB off (the tonemap tolerance) moves Y by at most one LSB and U/V by less
+            d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+            assert d.max() <= 1, f"yuv420 step {step} img {k}: max |diff| {d.max()}"
+            assert (d > 0).mean() < 0.02, f"yuv420 step {step} img {k}: {(d > 0).mean():.4f} of the bytes differ"
+
+
+def test_isp_reinhard_70_images_cross_the_chunk(ti, dev, rng):
+    """A 70-image list crosses the 64-image chunking of mi_isp_reinhard_batch / mi_isp_linear_batch."""
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=1.0, device=dev)
+    packs = [natural_packed12(rng, 48, 64, dark=0.004 * k) for k in range(70)]
+    imgs = [isp.load_packed12(torch.from_numpy(p).to(dev)) for p in packs]
+    refs = [im.cpu().numpy() for im in imgs]
+    lin = isp.tonemap_linear([im.clone() for im in imgs], gamma=0.9)
+    m = c_oracle.IspState(1.0).update_metering(refs)
+    for k in (0, 1, 63, 64, 65, 69):
+        assert_close(lin[k].cpu().numpy(), c_oracle.linear_isp(refs[k], m, 0.9), f"linear img {k}")
+    isp.metrics = None
+    outs = isp.tonemap_reinhard(imgs, gamma=0.7)
+    assert_close(isp.metrics.cpu().numpy(), m, "metrics of 70 images", rel=2e-5)
+    for k in range(70):
+        ref_u8, ref_after = c_oracle.reinhard_isp(refs[k], m, gamma=0.7)
+        assert_close(outs[k].cpu().numpy(), ref_u8, f"u8 img {k}")
+        assert_close(imgs[k].cpu().numpy(), ref_after, f"in-place p img {k}")
+
+
+@pytest.mark.parametrize("out", ["f16", "u8"])
+def test_pipeline12_4k_non_unit_bounds(ti, dev, scenes, out):
+    """Config 2 at full size on a frame whose demosaiced bounds are NOT (0, 1) (scene scaled into [0.1, 0.8]):
+    the general normalisation path of every pass, which no synthetic bench frame reaches, against the C oracle."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    packed = packed_from(scenes[2], 0.7, 0.1)
+    ref = c_oracle.pipeline12_reinhard(packed, work="f16", out=out)
+    cfa = c_oracle.decode12_scaled(packed, work="f16").reshape(3072, 4096)
+    rgb = c_oracle.demosaic(cfa, 0, round_f16=True)
+    assert rgb.min() > 0.0 and rgb.max() < 1.0, "the frame must not touch the clamp"
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=getattr(ti.types, out)).cpu().numpy()
+    assert_close(got, ref, f"pipeline12 4K non-unit bounds -> {out}")
