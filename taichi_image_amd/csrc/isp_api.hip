@@ -6,6 +6,7 @@
 #include "isp_elementwise.h"
 #include "isp_tile.h"
 #include "isp_resize_tile.h"
+#include "isp_stream.h"
 
 static thread_local char g_err[512] = "";
 
@@ -39,7 +40,7 @@ extern "C" int mi_isp_bayer_weights(int32_t out[4 * 13 * 3]) {
 
 extern "C" size_t mi_isp_workspace_bytes(int H, int W) {
   if (H <= 0 || W <= 0) return 0;
-  return (size_t)(FP_COUNT + 8 * (size_t)mi_partial_cap(H, W)) * sizeof(float);
+  return (size_t)(FP_COUNT + (size_t)strm::PART_ROWS * (size_t)mi_partial_cap(H, W)) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -90,6 +91,18 @@ static int packed_params(tile::Params& p, const uint8_t* packed, int H, int W, i
   return 0;
 }
 
+// The streaming kernels (isp_stream.h) take the standard 12-bit layout with aligned rows and whole 8-pixel units and
+// store through 16-byte units; everything else stays with the tile kernels.  MI_ISP_MEASURE builds can switch them
+// off (MI_ISP_NO_STREAM=1) to time the tile path.
+static bool use_stream(const tile::Params& p, int work_dtype, const void* out, int out_dtype) {
+#ifdef MI_ISP_MEASURE
+  static const bool off = getenv("MI_ISP_NO_STREAM") != nullptr;
+  if (off) return false;
+#endif
+  return strm::supported(p, work_dtype) && (!out || vec_store_ok(out, p.W, out_dtype)) &&
+         (int64_t)p.H * p.W * 3 * (int64_t)mi_dtype_size(out_dtype) < (int64_t)strm::INVALID_OFF;
+}
+
 extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,
                                   int pattern, const float* ccm9, int work_dtype, int Hd, int Wd, float scale,
                                   void* stream) {
@@ -109,6 +122,12 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
   }
   MI_REQUIRE(Hd == H && Wd == W, "load_packed: output shape must equal the frame when scale <= 0");
   p.vec_store = vec_store_ok(rgb, W, work_dtype);
+  if (use_stream(p, work_dtype, rgb, work_dtype)) {
+    strm::SArgs a = {};
+    a.t = p;
+    strm::geometry(H, W, a);
+    return strm::launch(a, work_dtype, pattern, strm::S_STORE, (hipStream_t)stream);
+  }
   return tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream);
 }
 
@@ -232,6 +251,32 @@ static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, fl
   return 0;
 }
 
+// The same chain on the streaming kernels: every pass re-derives the demosaiced image from the packed frame
+// (18.9 MB, served by L2 / Infinity Cache after the first pass) instead of writing and re-reading a 6 B/px
+// intermediate; HBM sees the packed frame in and the output out.  Pass A (S_BOUNDS) also accumulates the statistics
+// of tonemap.py:147-149 under the assumption that the bounds are exactly (0, 1) - true for every frame with a clipped
+// pixel at both ends - and pass B (S_STATS) returns at once when that held, so the usual frame costs three data
+// passes; any other frame gets the statistics from pass B.  The finalize steps are pulled into the consumers.
+// which: -1 = whole chain, 0..3 = one pass (measurement aid; the partials of a full run must be in the workspace).
+static int pipeline_frame_stream(tile::Params p, int pattern, int work_dtype, float intensity, float* ws, int which,
+                                 hipStream_t s) {
+  strm::SArgs a = {};
+  p.fp = ws; p.partials = ws + FP_COUNT; p.part_stride = mi_partial_cap(p.H, p.W);
+  a.t = p;
+  strm::geometry(p.H, p.W, a);
+  a.n_px = (float)((int64_t)p.H * p.W); a.intensity = intensity; a.fp_w = ws;
+  a.bounds_post = work_dtype == MI_F16 ? 2 : 1;
+  static const int epis[4] = {strm::S_BOUNDS, strm::S_STATS, strm::S_RH_MINMAX, strm::S_RH_STORE};
+  const PassTimer tm = which < 0 ? pass_timer(s) : PassTimer{0, false, s};
+  for (int k = 0; k < 4; ++k) {
+    if (which >= 0 && which != k) continue;
+    if (int rc = tm.begin(k)) return rc;
+    if (int rc = strm::launch(a, work_dtype, pattern, epis[k], s)) return rc;
+    if (int rc = tm.end(k)) return rc;
+  }
+  return 0;
+}
+
 static bool use_cached(const tile::Params& p, int work_dtype, int out_dtype) {
   static const bool off = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
   return !off && work_dtype == out_dtype && p.vec_store;
@@ -261,6 +306,10 @@ static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, 
                                color_adapt))
     return rc;
   if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, who)) return rc;
+  p.dst = out;
+  p.vec_store = vec_store_ok(out, W, out_dtype);
+  if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store)
+    return pipeline_frame_stream(p, pattern, work_dtype, intensity, ws, -1, s);
   static const bool no_cached = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
   void* image = work_dtype == out_dtype ? out : work_image;
   if (!no_cached && image && vec_store_ok(image, W, work_dtype))
@@ -315,6 +364,8 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
   float* fp = static_cast<float*>(ws);
+  if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && debug_skip == 0)
+    return pipeline_frame_stream(p, pattern, work_dtype, 1.0f, fp, pass, (hipStream_t)stream);
   if (use_cached(p, work_dtype, out_dtype) && debug_skip == 0)
     return pipeline_frame_cached(p, pattern, work_dtype, gamma, 1.0f, fp, pass, (hipStream_t)stream, out, out, out_dtype);
   p.fp = fp; p.partials = fp + FP_COUNT; p.part_stride = mi_partial_cap(H, W);

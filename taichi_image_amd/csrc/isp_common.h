@@ -35,6 +35,7 @@ void mi_set_error(const char* fmt, ...);   // defined in isp_api.hip (thread-loc
 static inline bool mi_valid_dtype(int d) { return d >= MI_U8 && d <= MI_F32; }
 static inline size_t mi_dtype_size(int d) { return d == MI_U8 ? 1 : (d == MI_F32 ? 4 : 2); }
 static inline float mi_scale_factor(int d) { return d == MI_U8 ? 255.f : (d == MI_U16 ? 65535.f : 1.f); }
+__host__ __device__ static inline size_t mi_dtype_size_dev(int d) { return d == MI_U8 ? 1 : (d == MI_F32 ? 4 : 2); }
 static inline bool mi_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // ---- device helpers ---------------------------------------------------------------------------
@@ -128,12 +129,13 @@ MI_DEV double wave_sum(double v) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
-// Block reduction of up to 8 values per thread for 256-thread blocks (4 waves): each wave
+// Block reduction of up to RW values per thread for 256-thread blocks (4 waves): each wave
 // shuffles down to one value, the per-wave results meet in LDS, thread k < NV combines them
 // and stores partial[k * stride + block].  op[k]: 0 = min, 1 = max, 2 = sum.
-template <int NV>
-MI_DEV void block_reduce_store(const float (&v)[NV], const int (&op)[NV], float (*red)[8],
+template <int NV, int RW>
+MI_DEV void block_reduce_store(const float (&v)[NV], const int (&op)[NV], float (*red)[RW],
                                float* partials, int stride, int block) {
+  static_assert(NV <= RW, "staging row too narrow");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {

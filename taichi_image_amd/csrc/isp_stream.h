@@ -1,0 +1,579 @@
+// Streaming Bayer demosaic for packed 12-bit frames: the register-resident form of bayer.py:115-177.
+//
+// One wave64 owns a band of 512 columns (8 pixels = one 12-byte packed unit per lane) and walks down
+// `rows_per_wave` rows of it.  Nothing of the stencil goes through LDS:
+//   * vertical taps: the six decoded CFA rows a row pair needs (r-2 .. r+3) stay in registers as a ring
+//     of 6 x 12 fp32 values per lane; each iteration decodes two new rows and retires two (the loop body
+//     exists in three rotations so that the ring is addressed statically, no register moves);
+//   * horizontal taps: the two pixels on either side of a lane's unit come from the neighbouring lanes
+//     with DPP wave shifts (v_mov_b32 wave_shr:1 / wave_shl:1), four moves per row; lanes 0 and 63 take
+//     them from one extra dword of the packed row instead;
+//   * packed rows are loaded three row pairs ahead of their use (global_load_dwordx3 per lane and row,
+//     contiguous across the wave) - the only wait in steady state is the one software-pipelined load;
+//   * no workgroup barrier: the four waves of a block are independent until the final reduction.
+// LDS is used only to transpose a wave's output row (64 lanes x 24 elements) into wave-contiguous
+// 16-byte stores (scratch/store_bench.hip: 6.2 vs 3.7 TB/s for the per-lane 3 x 16 B pattern).
+//
+// Arithmetic: identical to tile::tile_kernel (same accumulate<>, same border renormalisation table) and
+// therefore bit-exact against oracle/isp_oracle.py:bayer_to_rgb.
+//
+// Epilogues (one kernel per value): the passes of the fused config-2 chain (test/pipeline.py:26-32,
+// tonemap.py:135-168) that re-derive the demosaiced image from the packed frame instead of storing and
+// re-reading a 6 B/px intermediate, and the plain store of ISP.load_packed12 (camera_isp.py:333-340).
+#pragma once
+#include "isp_tile.h"
+#include "isp_finalize.h"
+
+#pragma clang fp contract(off)
+
+namespace strm {
+
+using tile::Params;
+using tile::static_for;
+
+constexpr int THREADS = 256, WAVES = THREADS / 64;
+constexpr int BAND = 512;                       // columns per wave: 64 lanes x 8 px
+constexpr int STAGE_U4 = 64 * 7;                // per-wave store staging: 64 lanes x 6 x 16 B (4-byte outputs), slot pitch 7
+
+enum Epi {
+  S_STORE = 0,         // demosaic -> work-dtype RGB image (ISP.load_packed12)
+  S_BOUNDS = 1,        // bounds of the work-dtype image (tonemap.py:146) + the statistics of :147-149 computed
+                       // on the assumption that the bounds turn out to be exactly (0, 1) (see S_STATS)
+  S_STATS = 2,         // statistics of the normalised image (tonemap.py:147-149) for bounds other than (0, 1):
+                       // exits at once when S_BOUNDS' assumption held
+  S_RH_MINMAX = 3,     // bounds of the Reinhard image (tonemap.py:150-153)
+  S_RH_STORE = 4,      // final map (tonemap.py:154), any output dtype
+  S_STORE_BOUNDS = 5   // S_STORE + S_BOUNDS in one pass (the "cached" chain's first pass)
+};
+
+// Partial rows (SoA, stride part_stride) a pass leaves, one entry per block:
+//   S_BOUNDS / S_STORE_BOUNDS: rows 0,1 = min,max; rows 2..8 = gmin,gmax,slog2,sgray,s0,s1,s2 (speculative)
+//   S_STATS:                   rows 2..8 (overwrites the speculative ones)
+//   S_RH_MINMAX:               rows 9,10
+constexpr int ROW_BOUNDS = 0, ROW_STATS = 2, ROW_BOUNDS2 = 9, PART_ROWS = 12;
+
+struct SArgs {
+  Params t;
+  int rows_per_wave;      // even
+  int bands_x, n_waves;
+  int n_blocks;           // == partial count of every pass of this geometry
+  float n_px, intensity;  // for the pulled finalize steps
+  float* fp_w;            // FrameParams (device), written by block 0 of the pulling passes
+  int bounds_post;        // FIN_BOUNDS post-processing of the raw bounds: 1 = clamp, 2 = clamp + f16 rounding
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave shifts: lane i takes the value of lane i-1 (shr) / i+1 (shl); lane 0 / lane 63 keep `old`
+// ---------------------------------------------------------------------------------------------
+MI_DEV float from_left(float v, float old) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+MI_DEV float from_right(float v, float old) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+
+// one packed row of this lane: d[0..2] = its 8 pixels, d[3] = the dword holding the two pixels beyond the
+// band's edge (lanes 0 and 63 only) -> window row: columns c0-2 .. c0+9 as work-dtype values in fp32
+template <class E>
+MI_DEV void decode_row(const uint32_t (&d)[4], bool ids, float k, int lane, float (&row)[12]) {
+  uint32_t v[8];
+  tile::unpack12x8(d[0], d[1], d[2], ids, v);
+  float own[8];
+  tile::decode_scaled8<E>(v, k, own);
+  // lane 0: the last pixel pair of the unit to the left = the upper 3 bytes of the dword before this unit;
+  // lane 63: the first pair of the unit to the right = the lower 3 bytes of the dword after it
+  const uint32_t w = lane == 0 ? d[3] >> 8 : d[3] & 0xFFFFFFu;
+  uint32_t e0, e1;
+  tile::unpack_pair(w, ids, e0, e1);
+  const float x0 = tile::decode_scaled<E>(e0, k), x1 = tile::decode_scaled<E>(e1, k);
+  row[0] = from_left(own[6], x0);
+  row[1] = from_left(own[7], x1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) row[2 + j] = own[j];
+  row[10] = from_right(own[0], x0);
+  row[11] = from_right(own[1], x1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-contiguous store of one output row of the band: lane l holds elements [24 l, 24 l + 24) as N 16-byte
+// (8-byte for u8) units.  The units leave through a raw buffer resource of the output image: `lane_off[j]` is the
+// byte offset of unit j * 64 + lane inside the band's row, or an offset beyond the image for units of lanes right
+// of it (such stores are dropped by the hardware - no branch around the store), `row_base` the byte offset of the
+// band's row (a scalar).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t INVALID_OFF = 0x40000000u;       // 1 GiB: beyond any frame the stream kernels accept
+
+template <int UB> MI_DEV void buffer_store_unit(__amdgpu_buffer_rsrc_t rsrc, const void* val, uint32_t voff, uint32_t soff) {
+  if constexpr (UB == 16) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 x; __builtin_memcpy(&x, val, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, voff, soff, 0);
+  } else {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    u2 x; __builtin_memcpy(&x, val, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(x, rsrc, voff, soff, 0);
+  }
+}
+
+template <class U, int N>
+MI_DEV void wave_store_units(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, const uint32_t (&lane_off)[6], int lane,
+                             uint4* stage_, const U (&mine)[N]) {
+  U* lb = reinterpret_cast<U*>(stage_);
+  // 6 units per lane (4-byte outputs): slots padded to 7 so that consecutive lanes' 16-byte writes fall into
+  // different bank groups (as tile::StagePitch)
+  constexpr int P = N == 6 ? 7 : N;
+#pragma unroll
+  for (int j = 0; j < N; ++j) lb[lane * P + j] = mine[j];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const int q = j * 64 + lane;
+    const int sl = N == 6 ? q / 6 : 0;
+    const U val = N == 6 ? lb[sl * P + (q - sl * 6)] : lb[q];
+    buffer_store_unit<(int)sizeof(U)>(rsrc, &val, lane_off[j], row_base);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class T>
+MI_DEV void wave_store_row_t(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, const uint32_t (&lane_off)[6], int lane,
+                             uint4* stage, const float (&v)[24]) {
+  typedef typename IoUnit<T>::type U;
+  constexpr int N = IoUnits<T>::value;
+  T o[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) o[i] = cast_out<T>(v[i]);
+  U mine[N];
+  __builtin_memcpy(mine, o, sizeof(mine));
+  wave_store_units<U, N>(rsrc, row_base, lane_off, lane, stage, mine);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pulled finalize: every block folds the producer's per-block partials itself (identical arithmetic in
+// every block) instead of a one-block launch between two passes; sh_fp = the FrameParams to work with.
+// FIN_BOUNDS: rows {min, max}; FIN_STATS: 7 rows; FIN_BOUNDS2: rows {min, max}.
+// ---------------------------------------------------------------------------------------------
+template <int FIN>
+MI_DEV void pull(const SArgs& a, const float* rows, float* sh_fp, double (*sh_tot)[WAVES]) {
+  constexpr int nrows = FIN == ew::FIN_STATS ? 7 : 2;
+  const float fp_mine = threadIdx.x < FP_COUNT ? a.t.fp[threadIdx.x] : 0.f;
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  constexpr int U = nrows == 2 ? 4 : 2;
+  for (int base = 0; base < a.n_blocks; base += U * THREADS) {
+    float v[U][nrows];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * THREADS + threadIdx.x;
+      const bool ok = i < a.n_blocks;
+#pragma unroll
+      for (int k = 0; k < nrows; ++k)
+        v[u][k] = ok ? rows[(size_t)k * a.t.part_stride + i] : (k == 0 ? __builtin_inff() : k == 1 ? -__builtin_inff() : 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mn = fminf(mn, v[u][0]); mx = fmaxf(mx, v[u][1]);
+#pragma unroll
+      for (int k = 2; k < nrows; ++k) sum[k - 2] += (double)v[u][k];
+    }
+  }
+  if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = fp_mine;
+  mn = wave_min(mn); mx = wave_max(mx);
+  if (nrows == 7) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sum[k] = wave_sum(sum[k]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh_tot[0][wave] = (double)mn; sh_tot[1][wave] = (double)mx;
+    if (nrows == 7) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sh_tot[k + 2][wave] = sum[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < nrows; ++k) {
+      double r = sh_tot[k][0];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) r = k == 0 ? fmin(r, sh_tot[k][w]) : (k == 1 ? fmax(r, sh_tot[k][w]) : r + sh_tot[k][w]);
+      tot[k] = r;
+    }
+    ew::FinArgs fa = {};
+    fa.fp = sh_fp; fa.n_px = a.n_px; fa.intensity = a.intensity; fa.la = a.t.la; fa.ca = a.t.ca;
+    fa.bounds_post = a.bounds_post;
+    ew::finalize_scalars<true>(FIN, fa, tot);
+  }
+  __syncthreads();
+}
+
+// the in-bounds weight sums in the constant address space: uniform indices become scalar loads
+__constant__ const tile::BorderTable BORDER_TC = tile::make_border_table();
+
+// ---- border renormalisation (bayer.py:143-155): v = acc * 16 / t for the pixels whose 13-tap diamond leaves the
+// image, t = the in-bounds weight sum (tile::BORDER_T).  No vector-memory lookups here: a load in this path would
+// make the wave drain its prefetched rows (s_waitcnt vmcnt(0)) - measured 3x on the edge bands of every frame.
+
+// x * 16 / T for a compile-time weight sum T: q = a * RN(1/T) with one exact residual step (a = 16 x).  Equal to the
+// IEEE quotient a / T for EVERY finite float a and every T that occurs (exhaustive check over all 2^32 bit patterns:
+// tests/test_oracle.py::test_border_division_by_reciprocal runs oracle/check_recip_div.c).
+template <int T> MI_DEV float div16_by(float x) {
+  if constexpr (T == 16) {
+    return x;
+  } else {
+    constexpr float d = (float)T, y = 1.0f / (float)T;
+    const float a = x * 16.f;
+    const float q = a * y;
+    const float e = __builtin_fmaf(-q, d, a);
+    return __builtin_fmaf(e, y, q);
+  }
+}
+
+// rows whose vertical taps are all inside the image: only pixels 0, 1 of the image's first unit (lane `is_left`) and
+// pixels 6, 7 of its last unit (`is_right`) are border pixels, and their weight sums are compile-time constants
+template <int PR, int PC, int I>
+MI_DEV void border_fix_cols(float (&v)[24], bool is_left, bool is_right, bool any_left, bool any_right) {
+  auto fix = [&](auto kc, auto cm, bool mine) {
+    constexpr int k = decltype(kc)::value, cmask = decltype(cm)::value;
+    constexpr int KIDX = ((I + PR) & 1) + 2 * ((k + PC) & 1);
+    constexpr uint32_t tq = tile::BORDER_T.t[KIDX][31][cmask];
+    static_for<0, 3>([&](auto cc) {
+      constexpr int ch = decltype(cc)::value;
+      constexpr int T = (int)(int8_t)(tq >> (8 * ch));
+      if constexpr (T != 16) v[3 * k + ch] = mine ? div16_by<T>(v[3 * k + ch]) : v[3 * k + ch];
+    });
+  };
+  if (any_left) {                                     // wave-uniform
+    fix(std::integral_constant<int, 0>{}, std::integral_constant<int, 28>{}, is_left);   // offsets -2, -1 outside
+    fix(std::integral_constant<int, 1>{}, std::integral_constant<int, 30>{}, is_left);   // offset -2 outside
+  }
+  if (any_right) {
+    fix(std::integral_constant<int, 6>{}, std::integral_constant<int, 15>{}, is_right);  // offset +2 outside
+    fix(std::integral_constant<int, 7>{}, std::integral_constant<int, 7>{}, is_right);   // offsets +1, +2 outside
+  }
+}
+
+// the image's first and last two rows (rmask != 31, wave-uniform): every pixel of the row is renormalised; the sums
+// come from the table through scalar loads (uniform index), one per lane kind
+template <int PR, int PC, int I>
+MI_DEV void border_fix_rows(float (&v)[24], int rmask, bool is_left, bool is_right) {
+  static_for<0, 8>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int KIDX = ((I + PR) & 1) + 2 * ((k + PC) & 1);
+    constexpr int cl = k == 0 ? 28 : k == 1 ? 30 : 31, cr = k == 6 ? 15 : k == 7 ? 7 : 31;
+    // three uniform (scalar) loads, then per-lane selects: a select between two table ADDRESSES would become a
+    // per-lane vector load
+    const uint32_t t_mid = __builtin_amdgcn_readfirstlane(BORDER_TC.t[KIDX][rmask][31]);
+    const uint32_t t_l = __builtin_amdgcn_readfirstlane(BORDER_TC.t[KIDX][rmask][cl]);
+    const uint32_t t_r = __builtin_amdgcn_readfirstlane(BORDER_TC.t[KIDX][rmask][cr]);
+    uint32_t tq = t_mid;
+    if constexpr (cl != 31) tq = is_left ? t_l : tq;
+    if constexpr (cr != 31) tq = is_right ? t_r : tq;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float t = (float)(int)(int8_t)(tq >> (8 * ch));
+      v[3 * k + ch] = (v[3 * k + ch] * 16.f) / t;     // t == 16: the value itself
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <class E, int PR, int PC, int EPI>
+__global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
+  constexpr bool EXACT = sizeof(E) == 2;
+  constexpr bool STORES = EPI == S_STORE || EPI == S_RH_STORE || EPI == S_STORE_BOUNDS;
+  constexpr bool BOUNDS = EPI == S_BOUNDS || EPI == S_STORE_BOUNDS;
+  const Params& p = a.t;
+  __shared__ __attribute__((aligned(16))) uint4 stage_all[STORES ? WAVES : 1][STORES ? STAGE_U4 : 1];
+  __shared__ float red[WAVES][16];
+  __shared__ float sh_fp[FP_COUNT];
+  __shared__ double sh_tot[7][WAVES];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // a scalar: the row arithmetic below is SALU work
+  const int g = blockIdx.x * WAVES + wave;
+  const bool wave_ok = g < a.n_waves;
+  const int by = g / a.bands_x, bx = g - by * a.bands_x;
+  const int c0 = bx * BAND + lane * 8;
+  const int r_begin = by * a.rows_per_wave;
+  const int r_end = wave_ok ? (r_begin + a.rows_per_wave < p.H ? r_begin + a.rows_per_wave : p.H) : r_begin;
+  const bool col_ok = wave_ok && c0 < p.W;
+  const int active_lanes = !wave_ok ? 0 : (p.W - bx * BAND >= BAND ? 64 : (p.W - bx * BAND) / 8);
+  constexpr bool ids = false;                          // the IDS layout stays with tile::tile_kernel (supported())
+  uint4* stage = stage_all[STORES ? wave : 0];
+
+  // Packed rows come through a raw buffer resource: an offset at or beyond the frame's size reads as zero, so rows
+  // above / below the image, lanes right of it and the edge dword of the 62 lanes that do not need one are all
+  // "loaded" by the same two unconditional instructions (no branches: the compiler can count the loads in flight,
+  // and zero bits decode to 0, i.e. out-of-image taps contribute 0 * w).  Offsets: a per-lane column part plus a
+  // per-row scalar part, either of which is INVALID (1 GiB, beyond any frame) when its coordinate is outside.
+  constexpr uint32_t INVALID = INVALID_OFF;
+  const uint32_t pitch = (uint32_t)p.W * 3 / 2;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
+  const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID;
+  // lane 0: the dword before its unit (pixels c0-2, c0-1 in its upper 3 bytes); lane 63: the dword after (c0+8, c0+9)
+  const bool ext_ok = col_ok && ((lane == 0 && c0 > 0) || (lane == 63 && c0 + 8 < p.W));
+  const uint32_t ext_off = ext_ok ? (uint32_t)c0 * 3 / 2 + (lane == 0 ? -4 : 12) : INVALID;
+
+  // output rows leave through a buffer resource too (wave_store_units): unit j * 64 + lane of the band's row
+  const int osz = EPI == S_RH_STORE ? (int)mi_dtype_size_dev(p.out_dtype) : (int)sizeof(E);
+  const int unit_bytes = osz == 1 ? 8 : 16, units_per_lane = 24 * osz / unit_bytes;
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.dst, 0, STORES ? (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz) : 0, 0x00020000);
+  uint32_t lane_off[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    lane_off[j] = (j * 64 + lane) < active_lanes * units_per_lane ? (uint32_t)(j * 64 + lane) * unit_bytes : INVALID_OFF;
+  const uint32_t out_pitch = (uint32_t)p.W * 3u * (uint32_t)osz, band_base = (uint32_t)bx * BAND * 3u * (uint32_t)osz;
+
+  auto load_row = [&](int r, uint32_t (&d)[4]) {
+    const uint32_t row_off = (r >= 0 && r < p.H && r < r_end + 2) ? (uint32_t)r * pitch : INVALID;     // scalar
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const u3 q = __builtin_amdgcn_raw_buffer_load_b96(rsrc, col_off + row_off, 0, 0);
+    d[0] = q.x; d[1] = q.y; d[2] = q.z;
+    d[3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ext_off + row_off, 0, 0);
+  };
+
+  // ---- prologue: every load of the first four window rows and of the first three row pairs in flight ----
+  if constexpr (EPI == S_STATS) {
+    // the bounds first: when S_BOUNDS' assumption held there is nothing to do (block 0 still publishes them)
+    pull<ew::FIN_BOUNDS>(a, p.partials + (size_t)ROW_BOUNDS * p.part_stride, sh_fp, sh_tot);
+    if (blockIdx.x == 0 && threadIdx.x < FP_COUNT && a.fp_w && ew::finalize_writes(ew::FIN_BOUNDS, threadIdx.x))
+      a.fp_w[threadIdx.x] = sh_fp[threadIdx.x];
+    if (sh_fp[FP_LO] == 0.f && sh_fp[FP_INV] == 1.f) return;
+  }
+  float win[6][12];                                  // ring: image row (r_begin - 2 + q) lives in slot q % 6
+  uint32_t raw[3][2][4];                             // ring: row pair j (rows r_begin + 2 + 2j, + 3 + 2j) in slot j % 3
+  {
+    uint32_t pro[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_row(r_begin - 2 + q, pro[q]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      load_row(r_begin + 2 + 2 * j, raw[j][0]);
+      load_row(r_begin + 3 + 2 * j, raw[j][1]);
+    }
+    // the pass's scalars while the loads fly
+    if constexpr (EPI == S_RH_MINMAX) pull<ew::FIN_STATS>(a, p.partials + (size_t)ROW_STATS * p.part_stride, sh_fp, sh_tot);
+    if constexpr (EPI == S_RH_STORE) pull<ew::FIN_BOUNDS2>(a, p.partials + (size_t)ROW_BOUNDS2 * p.part_stride, sh_fp, sh_tot);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) decode_row<E>(pro[q], ids, p.k_decode, lane, win[q]);
+  }
+
+  float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f;
+  ReinhardK rk;
+  rk.la = p.la; rk.ca = p.ca; rk.map_key = 1.f; rk.ei = 1.f; rk.mean3[0] = rk.mean3[1] = rk.mean3[2] = 0.f;
+  if constexpr (EPI == S_STATS || EPI == S_RH_MINMAX || EPI == S_RH_STORE) { lo = sh_fp[FP_LO]; inv = sh_fp[FP_INV]; }
+  if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
+    rk.map_key = sh_fp[FP_MAPKEY]; rk.ei = sh_fp[FP_EI];
+    rk.mean3[0] = sh_fp[FP_MEAN3]; rk.mean3[1] = sh_fp[FP_MEAN3 + 1]; rk.mean3[2] = sh_fp[FP_MEAN3 + 2];
+  }
+  if constexpr (EPI == S_RH_STORE) { lo2 = sh_fp[FP_LO2]; inv2 = sh_fp[FP_INV2]; }
+  // bounds exactly (0, 1): clamp((x - 0) * 1, 0, 1) is the identity on the clamped image
+  const bool unit = lo == 0.f && inv == 1.f;
+  if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
+    // block 0 publishes the pulled scalars for the passes after this one
+    constexpr int FIN = EPI == S_RH_MINMAX ? (int)ew::FIN_STATS : (int)ew::FIN_BOUNDS2;
+    if (blockIdx.x == 0 && threadIdx.x < FP_COUNT && a.fp_w && ew::finalize_writes(FIN, threadIdx.x))
+      a.fp_w[threadIdx.x] = sh_fp[threadIdx.x];
+  }
+
+  float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  StatsAcc st; st.init();
+
+  // the lanes holding the image's first / last unit of a row (their pixels 0, 1 / 6, 7 are border pixels)
+  const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
+  const bool any_left = __builtin_amdgcn_ballot_w64(is_left) != 0, any_right = __builtin_amdgcn_ballot_w64(is_right) != 0;
+
+  // ---- one row pair: rotation PH of the ring (PH = pair index % 3) ----
+  auto body = [&](auto ph_c, int i) {
+    constexpr int PH = decltype(ph_c)::value;
+    const int r = r_begin + 2 * i;
+    // the pair's two new window rows (image rows r + 2, r + 3), loaded three pairs ago
+    decode_row<E>(raw[PH][0], ids, p.k_decode, lane, win[(2 * PH + 4) % 6]);
+    decode_row<E>(raw[PH][1], ids, p.k_decode, lane, win[(2 * PH + 5) % 6]);
+    load_row(r + 8, raw[PH][0]);
+    load_row(r + 9, raw[PH][1]);
+    if (r >= r_end) return;                           // wave-uniform: a dead pair of the last rotation
+    float w6[6][12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int j = 0; j < 12; ++j) w6[k][j] = win[(2 * PH + k) % 6][j];
+
+    static_for<0, 2>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      const int row = r + I;
+      float v[24];
+      static_for<0, 8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int KIDX = ((I + PR) & 1) + 2 * ((k + PC) & 1);
+        float acc[3];
+        tile::accumulate<KIDX, EXACT, I, k>(p.wq, w6, acc);
+        v[3 * k] = acc[0]; v[3 * k + 1] = acc[1]; v[3 * k + 2] = acc[2];
+      });
+      if (row < 2 || row >= p.H - 2) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
+      else if (any_left || any_right) border_fix_cols<PR, PC, I>(v, is_left, is_right, any_left, any_right);
+      if (p.has_ccm) {                                // bayer.py:152-153, sequential fp32 dot
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float x = v[3 * k], y = v[3 * k + 1], z = v[3 * k + 2];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch)
+            v[3 * k + ch] = (p.ccm[3 * ch] * x + p.ccm[3 * ch + 1] * y) + p.ccm[3 * ch + 2] * z;
+        }
+      }
+      if constexpr (BOUNDS) {
+        // bounds of the work-dtype image: clamp (bayer.py:155) and rounding to E are monotone, so they are applied
+        // once to the reduced min / max (finalize, bounds_post), not to every pixel
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          vmin = fminf(vmin, fminf(v[3 * k], fminf(v[3 * k + 1], v[3 * k + 2])));
+          vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
+        }
+      }
+      // the demosaiced pixel as the reference materialises it: clamped, rounded to the work dtype
+      float t[24];
+      uint32_t pk[12];
+      if constexpr (sizeof(E) == 2) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) pk[j] = tile::cvt_pk_f16_clamp01(v[2 * j], v[2 * j + 1]);
+        if constexpr (EPI != S_STORE) {
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+            half_t h[2];
+            __builtin_memcpy(h, &pk[j], 4);
+            t[2 * j] = (float)h[0]; t[2 * j + 1] = (float)h[1];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) t[j] = clamp01(v[j]);
+      }
+      if constexpr (EPI == S_STORE || EPI == S_STORE_BOUNDS) {
+        const uint32_t row_base = (uint32_t)row * out_pitch + band_base;
+        if constexpr (sizeof(E) == 2) {
+          uint4 mine[3];
+          __builtin_memcpy(mine, pk, sizeof(mine));
+          wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
+        } else {
+          uint4 mine[6];
+          __builtin_memcpy(mine, t, sizeof(mine));
+          wave_store_units<uint4, 6>(drsrc, row_base, lane_off, lane, stage, mine);
+        }
+      }
+      if constexpr (BOUNDS) {
+        // statistics of tonemap.py:147-149 on the assumption lo = 0, hi = 1 (norm01 is then the identity)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st.add(t[3 * k], t[3 * k + 1], t[3 * k + 2]);
+      }
+      if constexpr (EPI == S_STATS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          st.add(norm01(t[3 * k], lo, inv), norm01(t[3 * k + 1], lo, inv), norm01(t[3 * k + 2], lo, inv));
+      }
+      if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
+        auto tone = [&](auto unit_c, auto ca0_c) {
+          constexpr bool UNIT = decltype(unit_c)::value, CA0 = decltype(ca0_c)::value;
+          float o[24];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float x[3], q[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm01(t[3 * k + ch], lo, inv);
+            reinhard_px<CA0>(x, rk, q);
+            if constexpr (EPI == S_RH_MINMAX) {
+              vmin = fminf(vmin, fminf(q[0], fminf(q[1], q[2])));
+              vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = q[ch];
+            }
+          }
+          if constexpr (EPI == S_RH_STORE) {
+            linear_n<24>(o, lo2, inv2, p.gamma_inv, p.out_scale);                   // tonemap.py:154
+            const uint32_t row_base = (uint32_t)row * out_pitch + band_base;
+            switch (p.out_dtype) {
+              case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, o); break;
+              case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, o); break;
+              case MI_F16: wave_store_row_t<half_t>(drsrc, row_base, lane_off, lane, stage, o); break;
+              default: wave_store_row_t<float>(drsrc, row_base, lane_off, lane, stage, o); break;
+            }
+          }
+        };
+        if (rk.ca == 0.f) {
+          if (unit) tone(std::true_type{}, std::true_type{});
+          else tone(std::false_type{}, std::true_type{});
+        } else {
+          tone(std::false_type{}, std::false_type{});
+        }
+      }
+    });
+  };
+
+  const int n_pairs = (r_end - r_begin) / 2;
+  for (int i = 0; i < n_pairs; i += 3) {
+    body(std::integral_constant<int, 0>{}, i);
+    body(std::integral_constant<int, 1>{}, i + 1);
+    body(std::integral_constant<int, 2>{}, i + 2);
+  }
+
+  // ---- reductions: one partial per block ----
+  if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }   // lanes beyond the image saw zeros
+  if constexpr (BOUNDS) {
+    const float v9[9] = {vmin, vmax, st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
+    const int op[9] = {0, 1, 0, 1, 2, 2, 2, 2, 2};
+    block_reduce_store<9>(v9, op, red, p.partials + (size_t)ROW_BOUNDS * p.part_stride, p.part_stride, blockIdx.x);
+  } else if constexpr (EPI == S_STATS) {
+    const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
+    const int op[7] = {0, 1, 2, 2, 2, 2, 2};
+    block_reduce_store<7>(v7, op, red, p.partials + (size_t)ROW_STATS * p.part_stride, p.part_stride, blockIdx.x);
+  } else if constexpr (EPI == S_RH_MINMAX) {
+    const float v2[2] = {vmin, vmax};
+    const int op[2] = {0, 1};
+    block_reduce_store<2>(v2, op, red, p.partials + (size_t)ROW_BOUNDS2 * p.part_stride, p.part_stride, blockIdx.x);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+// geometry: bands of 512 columns; rows per wave chosen so that the grid holds about 2 waves per SIMD
+static inline void geometry(int H, int W, SArgs& a) {
+  a.bands_x = (W + BAND - 1) / BAND;
+  const int target_waves = 2048;
+  int rpw = (int)(((long)H * a.bands_x + target_waves - 1) / target_waves);
+  rpw = (rpw + 5) / 6 * 6;                            // whole rotations of the row ring
+  if (rpw < 6) rpw = 6;
+  a.rows_per_wave = rpw;
+  const int bands_y = (H + rpw - 1) / rpw;
+  a.n_waves = a.bands_x * bands_y;
+  a.n_blocks = (a.n_waves + WAVES - 1) / WAVES;
+}
+
+// what the stream kernels handle: 12-bit packed sources in the standard layout with 4-byte aligned rows, whole
+// 8-pixel units, unit scale, frames below 1 GiB (the rest stays with tile::tile_kernel)
+static inline bool supported(const Params& p, int work_dtype) {
+  return p.src_kind == tile::SRC_PACKED12 && p.src_fast && p.W % 8 == 0 && p.H % 2 == 0 && p.in_scale == 1.f &&
+         (work_dtype == MI_F16 || work_dtype == MI_F32) && (int64_t)p.H * p.W * 3 / 2 < (int64_t)0x40000000;
+}
+
+int launch_rggb(const SArgs& a, int work_dtype, int epi, hipStream_t stream);
+int launch_grbg(const SArgs& a, int work_dtype, int epi, hipStream_t stream);
+int launch_gbrg(const SArgs& a, int work_dtype, int epi, hipStream_t stream);
+int launch_bggr(const SArgs& a, int work_dtype, int epi, hipStream_t stream);
+static inline int launch(const SArgs& a, int work_dtype, int pattern, int epi, hipStream_t stream) {
+  switch (pattern) {
+    case MI_RGGB: return launch_rggb(a, work_dtype, epi, stream);
+    case MI_GRBG: return launch_grbg(a, work_dtype, epi, stream);
+    case MI_GBRG: return launch_gbrg(a, work_dtype, epi, stream);
+    default: return launch_bggr(a, work_dtype, epi, stream);
+  }
+}
+
+}  // namespace strm
