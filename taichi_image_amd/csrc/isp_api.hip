@@ -40,6 +40,9 @@ extern "C" int mi_isp_bayer_weights(int32_t out[4 * 13 * 3]) {
 
 extern "C" size_t mi_isp_workspace_bytes(int H, int W) {
   if (H <= 0 || W <= 0) return 0;
+#ifdef MI_STREAM_STAMPS
+  return (size_t)(FP_COUNT + ((size_t)strm::PART_ROWS + 16) * (size_t)mi_partial_cap(H, W)) * sizeof(float);
+#endif
   return (size_t)(FP_COUNT + (size_t)strm::PART_ROWS * (size_t)mi_partial_cap(H, W)) * sizeof(float);
 }
 
@@ -233,11 +236,21 @@ static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, fl
   p.out_dtype = work_dtype; p.out_scale = 1.f;
   const PassTimer tm = which < 0 ? pass_timer(s) : PassTimer{0, false, s};
   if (int rc = tm.begin(0)) return rc;
-  if (which < 0 || which == 0)
+  int n_bounds = tile::num_tiles(p.H, p.W);
+  const bool stream0 = use_stream(p, work_dtype, image, work_dtype);
+  if (stream0) {
+    strm::SArgs a = {};
+    a.t = p;
+    strm::geometry(p.H, p.W, a);
+    n_bounds = a.n_blocks;
+    if (which < 0 || which == 0)
+      if (int rc = strm::launch(a, work_dtype, pattern, strm::S_STORE_BOUNDS, s)) return rc;
+  } else if (which < 0 || which == 0) {
     if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STORE_MINMAX, s)) return rc;   // bayer.py + tonemap.py:146
+  }
   if (int rc = tm.end(0)) return rc;
   if (which == 0) return 0;
-  const ew::PullSrc bounds = {partials, cap, tile::num_tiles(p.H, p.W), work_dtype == MI_F16 ? 2 : 1};
+  const ew::PullSrc bounds = {partials, cap, n_bounds, work_dtype == MI_F16 ? 2 : 1};
   if (which > 0)
     return ew::tonemap_reinhard_tail(image, out, p.H, p.W, work_dtype, out_dtype, gamma, intensity, p.la, p.ca, ws,
                                      which, bounds, s);
@@ -277,6 +290,16 @@ static int pipeline_frame_stream(tile::Params p, int pattern, int work_dtype, fl
   return 0;
 }
 
+// measurement aid: MI_ISP_PIPELINE=cached times the store-and-re-read chain on the same build
+static bool force_cached() {
+#ifdef MI_ISP_MEASURE
+  static const bool on = getenv("MI_ISP_PIPELINE") && !strcmp(getenv("MI_ISP_PIPELINE"), "cached");
+  return on;
+#else
+  return false;
+#endif
+}
+
 static bool use_cached(const tile::Params& p, int work_dtype, int out_dtype) {
   static const bool off = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
   return !off && work_dtype == out_dtype && p.vec_store;
@@ -308,7 +331,7 @@ static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, 
   if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, who)) return rc;
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
-  if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store)
+  if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && !force_cached())
     return pipeline_frame_stream(p, pattern, work_dtype, intensity, ws, -1, s);
   static const bool no_cached = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
   void* image = work_dtype == out_dtype ? out : work_image;
@@ -364,7 +387,7 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
   float* fp = static_cast<float*>(ws);
-  if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && debug_skip == 0)
+  if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && debug_skip == 0 && !force_cached())
     return pipeline_frame_stream(p, pattern, work_dtype, 1.0f, fp, pass, (hipStream_t)stream);
   if (use_cached(p, work_dtype, out_dtype) && debug_skip == 0)
     return pipeline_frame_cached(p, pattern, work_dtype, gamma, 1.0f, fp, pass, (hipStream_t)stream, out, out, out_dtype);

@@ -23,6 +23,7 @@
 #pragma once
 #include "isp_tile.h"
 #include "isp_finalize.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -74,26 +75,82 @@ MI_DEV float from_right(float v, float old) {
                                                                 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
 }
 
+// VALU cost model of gfx950 these kernels are written to (scratch/occ_bench.hip, scratch/issue_bench.hip; cycles of
+// one SIMD per wave64 instruction with two or more waves resident, ~2.1 GHz under load):
+//   2 cycles: VOP1 / VOP2 encodings with VGPR, literal or inline-constant operands - v_fmac/mul/add/sub_f32, v_and/or,
+//             shifts, v_mov, v_add_u32, v_fmamk/fmaak;
+//   4 cycles: everything else - any instruction with an SGPR operand, VOP3 / VOP3P / SDWA / DPP forms, v_min/max(3),
+//             every v_cvt_*, v_bfe, v_perm, v_alignbit, v_fma_mix_f32 (the f16-window variant of this kernel that read
+//             halves through v_fma_mix ran no faster than converting once: half-rate instructions);
+//   8 cycles: v_log/exp/rcp_f32.
+// So: weights and scalars live in VGPRs, the window is fp32 and the 21 FMAs per pixel are plain v_fmac_f32.
+
+// the eight distinct demosaic weights / 16, in tile::wq_index order
+__host__ __device__ constexpr float wq_value(int i) {
+  return (i == 0 ? -3.f : i == 1 ? -2.f : i == 2 ? 1.f : i == 3 ? 4.f : i == 4 ? 8.f : i == 5 ? 10.f : i == 6 ? 12.f : 16.f) * 0.0625f;
+}
+
+// an opaque VGPR copy of a uniform value: keeps the compiler from folding it back into an SGPR / literal operand
+MI_DEV float vgpr(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+
+// The window row of a lane: image columns c0-2 .. c0+9 of one row, work-dtype values widened to fp32.
+struct WinRow { float v[12]; };
+
 // one packed row of this lane: d[0..2] = its 8 pixels, d[3] = the dword holding the two pixels beyond the
-// band's edge (lanes 0 and 63 only) -> window row: columns c0-2 .. c0+9 as work-dtype values in fp32
-template <class E>
-MI_DEV void decode_row(const uint32_t (&d)[4], bool ids, float k, int lane, float (&row)[12]) {
+// band's edge (lanes 0 and 63 only) -> window row.  The scaled decode of packed.py:98-100 - f32(v) * f32(1/4095),
+// rounded to the work dtype, widened back - has 4096 possible results: they are tabulated once per block in LDS
+// (16 KB, filled with exactly that arithmetic) and a pixel costs one ds_read_b32 instead of four half-rate
+// conversions; the table index is the unpacked 12-bit value itself.
+MI_DEV void decode_row(const uint32_t (&d)[4], const float (&lut)[4096], int lane, WinRow& row) {
   uint32_t v[8];
-  tile::unpack12x8(d[0], d[1], d[2], ids, v);
-  float own[8];
-  tile::decode_scaled8<E>(v, k, own);
+  tile::unpack12x8(d[0], d[1], d[2], false, v);
   // lane 0: the last pixel pair of the unit to the left = the upper 3 bytes of the dword before this unit;
   // lane 63: the first pair of the unit to the right = the lower 3 bytes of the dword after it
   const uint32_t w = lane == 0 ? d[3] >> 8 : d[3] & 0xFFFFFFu;
-  uint32_t e0, e1;
-  tile::unpack_pair(w, ids, e0, e1);
-  const float x0 = tile::decode_scaled<E>(e0, k), x1 = tile::decode_scaled<E>(e1, k);
-  row[0] = from_left(own[6], x0);
-  row[1] = from_left(own[7], x1);
+  float own[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) row[2 + j] = own[j];
-  row[10] = from_right(own[0], x0);
-  row[11] = from_right(own[1], x1);
+  for (int i = 0; i < 8; ++i) own[i] = lut[v[i]];
+  const float x0 = lut[w & 0xFFFu], x1 = lut[w >> 12];
+  row.v[0] = from_left(own[6], x0);
+  row.v[1] = from_left(own[7], x1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) row.v[2 + j] = own[j];
+  row.v[10] = from_right(own[0], x0);
+  row.v[11] = from_right(own[1], x1);
+}
+
+// filter_at (bayer.py:138-155) for the 8 pixels of strip row I of a 6-row window: per pixel and channel a sequential
+// fp32 accumulation over the non-zero taps in reference order with the weights w/16 (as tile::accumulate).  The loop
+// nest is taps outermost, pixels and channels inside: consecutive instructions belong to different accumulation
+// chains (up to 24 of them), so no instruction waits for its predecessor's result; within each chain the order of
+// the additions is unchanged.  wq: the eight distinct weights / 16 in VGPRs (tile::wq_index).
+template <int PR, int PC, int I, bool EXACT>
+MI_DEV void accumulate_row(const WinRow (&win)[6], const float (&wq)[8], float (&v)[24]) {
+  bool first[24];
+#pragma unroll
+  for (int j = 0; j < 24; ++j) first[j] = true;
+  static_for<0, 13>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int row = I + 2 + tile::TAP_DR[t];
+    static_for<0, 8>([&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      constexpr int KIDX = ((I + PR) & 1) + 2 * ((K + PC) & 1);
+      constexpr int col = K + 2 + tile::TAP_DC[t];
+      static_for<0, 3>([&](auto cc) {
+        constexpr int ch = decltype(cc)::value;
+        constexpr int wi = tile::KW[KIDX][t][ch];
+        if constexpr (wi != 0) {
+          const float w = wq[tile::wq_index(wi)];
+          const float x = win[row].v[col];
+          float& acc = v[3 * K + ch];
+          if (first[3 * K + ch]) acc = x * w;                               // == fma(x, w, +0)
+          else if constexpr (EXACT) acc = __builtin_fmaf(x, w, acc);
+          else acc = acc + x * w;
+          first[3 * K + ch] = false;
+        }
+      });
+    });
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -148,6 +205,66 @@ MI_DEV void wave_store_row_t(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, con
   U mine[N];
   __builtin_memcpy(mine, o, sizeof(mine));
   wave_store_units<U, N>(rsrc, row_base, lane_off, lane, stage, mine);
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics of tonemap.py:78-103, two pixels per call.  min / max are taken on the gray values themselves and the
+// clamp max(gray, 1e-4) (monotone) is applied once to the reduced values; the channel sums are only accumulated when
+// something consumes them (RGB: color_adapt != 0 - otherwise mean3 == gray_mean, tonemap.py:119).
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(fast)
+struct Stats2 {
+  float gmin, gmax, slog, sgray, s0, s1, s2;
+  MI_DEV void init() {
+    gmin = __builtin_inff(); gmax = -__builtin_inff();
+    slog = sgray = s0 = s1 = s2 = 0.f;
+  }
+  template <bool RGB>
+  MI_DEV void add2(float a0, float a1, float a2, float b0, float b1, float b2) {
+    const float ga = rgb_gray(a0, a1, a2), gb = rgb_gray(b0, b1, b2);
+    gmin = __builtin_fminf(gmin, __builtin_fminf(ga, gb));          // v_min3_f32
+    gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(ga, gb));
+    slog += hw_log2(fmaxf(ga, 1e-4f));            // sum of log2; scaled by ln2 when combined
+    slog += hw_log2(fmaxf(gb, 1e-4f));
+    sgray += ga; sgray += gb;
+    if constexpr (RGB) { s0 += a0; s0 += b0; s1 += a1; s1 += b1; s2 += a2; s2 += b2; }
+  }
+  MI_DEV void finish() { gmin = fmaxf(gmin, 1e-4f); gmax = fmaxf(gmax, 1e-4f); }
+};
+#pragma clang fp contract(off)
+
+// Block reduction without a barrier: every wave reduces its values in registers (DPP), leaves them in its own LDS
+// row and counts itself in; the wave that arrives last combines the rows in wave order (deterministic) and stores the
+// block's partial.  Waves that finish early retire instead of waiting for the slowest one (the edge bands).
+// `arrived` must be zero before the first arrival (set by the kernel prologue, followed by its only barrier).
+template <int NV>
+MI_DEV void block_reduce_store_nb(const float (&v)[NV], const int (&op)[NV], float (*red)[16], unsigned* arrived,
+                                  float* partials, int stride, int block, int wave, int lane) {
+  static_assert(NV <= 16, "staging row too narrow");
+  float r[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) r[k] = op[k] == 0 ? wave_min(v[k]) : (op[k] == 1 ? wave_max(v[k]) : wave_sum(v[k]));
+  unsigned before = 0;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[wave][k] = r[k];
+    before = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  before = __builtin_amdgcn_readfirstlane(before);
+  if (before == WAVES - 1) {                          // wave-uniform: this wave arrived last
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float x = red[0][k];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) {
+        const float o = red[w][k];
+        x = op[k] == 0 ? fminf(x, o) : (op[k] == 1 ? fmaxf(x, o) : x + o);
+      }
+      mine = lane == k ? x : mine;
+    }
+    if (lane < NV) partials[(size_t)lane * stride + block] = mine;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,6 +401,19 @@ MI_DEV void border_fix_rows(float (&v)[24], int rmask, bool is_left, bool is_rig
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
+// measurement aid (make EXTRA=-DMI_STREAM_STAMPS): lane 0 of every wave leaves s_memtime stamps of its phases in the
+// workspace behind the partial rows (16 per wave, 32-bit); see scripts/stream_stamps.py
+#ifdef MI_STREAM_STAMPS
+#define MI_SSTAMP(i)                                                                                          \
+  do {                                                                                                        \
+    if (lane == 0 && wave_ok)                                                                                 \
+      reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride)[g * 16 + (i)] =             \
+          (unsigned)__builtin_readcyclecounter();                                                             \
+  } while (0)
+#else
+#define MI_SSTAMP(i) do {} while (0)
+#endif
+
 template <class E, int PR, int PC, int EPI>
 __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   constexpr bool EXACT = sizeof(E) == 2;
@@ -294,6 +424,9 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   __shared__ float red[WAVES][16];
   __shared__ float sh_fp[FP_COUNT];
   __shared__ double sh_tot[7][WAVES];
+  __shared__ unsigned arrived;
+  __shared__ float lut[4096];                         // the decoded value of every 12-bit code (decode_row)
+  if (threadIdx.x == 0) arrived = 0;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // a scalar: the row arithmetic below is SALU work
@@ -305,7 +438,6 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   const int r_end = wave_ok ? (r_begin + a.rows_per_wave < p.H ? r_begin + a.rows_per_wave : p.H) : r_begin;
   const bool col_ok = wave_ok && c0 < p.W;
   const int active_lanes = !wave_ok ? 0 : (p.W - bx * BAND >= BAND ? 64 : (p.W - bx * BAND) / 8);
-  constexpr bool ids = false;                          // the IDS layout stays with tile::tile_kernel (supported())
   uint4* stage = stage_all[STORES ? wave : 0];
 
   // Packed rows come through a raw buffer resource: an offset at or beyond the frame's size reads as zero, so rows
@@ -341,6 +473,7 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
     d[3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ext_off + row_off, 0, 0);
   };
 
+  MI_SSTAMP(0);
   // ---- prologue: every load of the first four window rows and of the first three row pairs in flight ----
   if constexpr (EPI == S_STATS) {
     // the bounds first: when S_BOUNDS' assumption held there is nothing to do (block 0 still publishes them)
@@ -349,7 +482,11 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
       a.fp_w[threadIdx.x] = sh_fp[threadIdx.x];
     if (sh_fp[FP_LO] == 0.f && sh_fp[FP_INV] == 1.f) return;
   }
-  float win[6][12];                                  // ring: image row (r_begin - 2 + q) lives in slot q % 6
+  // uniform operands of the hot loop as VGPRs (an SGPR operand halves a VALU instruction's rate)
+  float wq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wq[i] = vgpr(wq_value(i));
+  WinRow win[6];                                     // ring: image row (r_begin - 2 + q) lives in slot q % 6
   uint32_t raw[3][2][4];                             // ring: row pair j (rows r_begin + 2 + 2j, + 3 + 2j) in slot j % 3
   {
     uint32_t pro[4][4];
@@ -360,12 +497,16 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
       load_row(r_begin + 2 + 2 * j, raw[j][0]);
       load_row(r_begin + 3 + 2 * j, raw[j][1]);
     }
+    for (int e = threadIdx.x; e < 4096; e += THREADS) lut[e] = tile::decode_scaled<E>((uint32_t)e, p.k_decode);
+    MI_SSTAMP(1);
+    __syncthreads();                                  // the table is complete, `arrived` is zero for everyone; the kernel's only barrier besides pull()
     // the pass's scalars while the loads fly
     if constexpr (EPI == S_RH_MINMAX) pull<ew::FIN_STATS>(a, p.partials + (size_t)ROW_STATS * p.part_stride, sh_fp, sh_tot);
     if constexpr (EPI == S_RH_STORE) pull<ew::FIN_BOUNDS2>(a, p.partials + (size_t)ROW_BOUNDS2 * p.part_stride, sh_fp, sh_tot);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) decode_row<E>(pro[q], ids, p.k_decode, lane, win[q]);
+    for (int q = 0; q < 4; ++q) decode_row(pro[q], lut, lane, win[q]);
   }
+  MI_SSTAMP(2);
 
   float lo = 0.f, inv = 1.f, lo2 = 0.f, inv2 = 1.f;
   ReinhardK rk;
@@ -386,7 +527,8 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   }
 
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
-  StatsAcc st; st.init();
+  Stats2 st; st.init();
+  const bool want_rgb = p.ca != 0.f;                 // channel means feed mean3 only then (tonemap.py:119)
 
   // the lanes holding the image's first / last unit of a row (their pixels 0, 1 / 6, 7 are border pixels)
   const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
@@ -397,30 +539,25 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
     constexpr int PH = decltype(ph_c)::value;
     const int r = r_begin + 2 * i;
     // the pair's two new window rows (image rows r + 2, r + 3), loaded three pairs ago
-    decode_row<E>(raw[PH][0], ids, p.k_decode, lane, win[(2 * PH + 4) % 6]);
-    decode_row<E>(raw[PH][1], ids, p.k_decode, lane, win[(2 * PH + 5) % 6]);
+    decode_row(raw[PH][0], lut, lane, win[(2 * PH + 4) % 6]);
+    decode_row(raw[PH][1], lut, lane, win[(2 * PH + 5) % 6]);
     load_row(r + 8, raw[PH][0]);
     load_row(r + 9, raw[PH][1]);
     if (r >= r_end) return;                           // wave-uniform: a dead pair of the last rotation
-    float w6[6][12];
+    WinRow w6[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-      for (int j = 0; j < 12; ++j) w6[k][j] = win[(2 * PH + k) % 6][j];
+    for (int k = 0; k < 6; ++k) w6[k] = win[(2 * PH + k) % 6];
 
     static_for<0, 2>([&](auto ic) {
       constexpr int I = decltype(ic)::value;
       const int row = r + I;
       float v[24];
-      static_for<0, 8>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int KIDX = ((I + PR) & 1) + 2 * ((k + PC) & 1);
-        float acc[3];
-        tile::accumulate<KIDX, EXACT, I, k>(p.wq, w6, acc);
-        v[3 * k] = acc[0]; v[3 * k + 1] = acc[1]; v[3 * k + 2] = acc[2];
-      });
+      accumulate_row<PR, PC, I, EXACT>(w6, wq, v);
+#ifndef MI_STREAM_ANALYZE   /* reading aid: the hot path alone (scratch compile only) */
       if (row < 2 || row >= p.H - 2) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
       else if (any_left || any_right) border_fix_cols<PR, PC, I>(v, is_left, is_right, any_left, any_right);
+#endif
+#ifndef MI_STREAM_ANALYZE
       if (p.has_ccm) {                                // bayer.py:152-153, sequential fp32 dot
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -430,6 +567,7 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
             v[3 * k + ch] = (p.ccm[3 * ch] * x + p.ccm[3 * ch + 1] * y) + p.ccm[3 * ch + 2] * z;
         }
       }
+#endif
       if constexpr (BOUNDS) {
         // bounds of the work-dtype image: clamp (bayer.py:155) and rounding to E are monotone, so they are applied
         // once to the reduced min / max (finalize, bounds_post), not to every pixel
@@ -471,13 +609,20 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
       }
       if constexpr (BOUNDS) {
         // statistics of tonemap.py:147-149 on the assumption lo = 0, hi = 1 (norm01 is then the identity)
+        if (want_rgb) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) st.add(t[3 * k], t[3 * k + 1], t[3 * k + 2]);
+          for (int k = 0; k < 8; k += 2) st.add2<true>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) st.add2<false>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+        }
       }
       if constexpr (EPI == S_STATS) {
+        float n[24];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          st.add(norm01(t[3 * k], lo, inv), norm01(t[3 * k + 1], lo, inv), norm01(t[3 * k + 2], lo, inv));
+        for (int j = 0; j < 24; ++j) n[j] = norm01(t[j], lo, inv);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) st.add2<true>(n[3 * k], n[3 * k + 1], n[3 * k + 2], n[3 * k + 3], n[3 * k + 4], n[3 * k + 5]);
       }
       if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
         auto tone = [&](auto unit_c, auto ca0_c) {
@@ -521,24 +666,32 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   const int n_pairs = (r_end - r_begin) / 2;
   for (int i = 0; i < n_pairs; i += 3) {
     body(std::integral_constant<int, 0>{}, i);
+    MI_SSTAMP(3 + (i < 9 ? i : 9));
     body(std::integral_constant<int, 1>{}, i + 1);
+    MI_SSTAMP(4 + (i < 9 ? i : 9));
     body(std::integral_constant<int, 2>{}, i + 2);
+    MI_SSTAMP(5 + (i < 9 ? i : 9));
   }
+  MI_SSTAMP(15);
 
   // ---- reductions: one partial per block ----
+  st.finish();
   if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }   // lanes beyond the image saw zeros
   if constexpr (BOUNDS) {
     const float v9[9] = {vmin, vmax, st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[9] = {0, 1, 0, 1, 2, 2, 2, 2, 2};
-    block_reduce_store<9>(v9, op, red, p.partials + (size_t)ROW_BOUNDS * p.part_stride, p.part_stride, blockIdx.x);
+    block_reduce_store_nb<9>(v9, op, red, &arrived, p.partials + (size_t)ROW_BOUNDS * p.part_stride, p.part_stride,
+                             blockIdx.x, wave, lane);
   } else if constexpr (EPI == S_STATS) {
     const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[7] = {0, 1, 2, 2, 2, 2, 2};
-    block_reduce_store<7>(v7, op, red, p.partials + (size_t)ROW_STATS * p.part_stride, p.part_stride, blockIdx.x);
+    block_reduce_store_nb<7>(v7, op, red, &arrived, p.partials + (size_t)ROW_STATS * p.part_stride, p.part_stride,
+                             blockIdx.x, wave, lane);
   } else if constexpr (EPI == S_RH_MINMAX) {
     const float v2[2] = {vmin, vmax};
     const int op[2] = {0, 1};
-    block_reduce_store<2>(v2, op, red, p.partials + (size_t)ROW_BOUNDS2 * p.part_stride, p.part_stride, blockIdx.x);
+    block_reduce_store_nb<2>(v2, op, red, &arrived, p.partials + (size_t)ROW_BOUNDS2 * p.part_stride, p.part_stride,
+                             blockIdx.x, wave, lane);
   }
 }
 
@@ -546,10 +699,14 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
 // geometry: bands of 512 columns; rows per wave chosen so that the grid holds about 2 waves per SIMD
 static inline void geometry(int H, int W, SArgs& a) {
   a.bands_x = (W + BAND - 1) / BAND;
-  const int target_waves = 2048;
+  int target_waves = 2048;
+#ifdef MI_ISP_MEASURE
+  static const int env_waves = getenv("MI_ISP_STREAM_WAVES") ? atoi(getenv("MI_ISP_STREAM_WAVES")) : 0;
+  if (env_waves > 0) target_waves = env_waves;
+#endif
   int rpw = (int)(((long)H * a.bands_x + target_waves - 1) / target_waves);
-  rpw = (rpw + 5) / 6 * 6;                            // whole rotations of the row ring
-  if (rpw < 6) rpw = 6;
+  rpw = (rpw + 1) / 2 * 2;                            // whole row pairs (a last, partial rotation of the ring skips its dead pairs)
+  if (rpw < 4) rpw = 4;
   a.rows_per_wave = rpw;
   const int bands_y = (H + rpw - 1) / rpw;
   a.n_waves = a.bands_x * bands_y;
