@@ -16,7 +16,9 @@
  *  - every function returns 0 on success, non-zero on failure; the message for the calling
  *    thread is available from mi_isp_last_error();
  *  - `ws_dev` is a scratch buffer of at least mi_isp_workspace_bytes(H, W) bytes, private to
- *    one in-flight call (use one per stream / per frame in flight).
+ *    one in-flight call (use one per stream / per frame in flight).  It must be ZERO-FILLED once
+ *    before its first use (hipMemset): the whole-frame kernel of mi_isp_pipeline12_reinhard keeps its
+ *    grid-barrier counters there and leaves them zero again at the end of every launch.
  */
 #ifndef MI_ISP_H
 #define MI_ISP_H
@@ -49,6 +51,12 @@ int mi_isp_bayer_weights(int32_t out[4 * 13 * 3]);
 
 /* Scratch bytes needed by the calls that take ws_dev, for an H x W frame. */
 size_t mi_isp_workspace_bytes(int H, int W);
+
+/* Byte offset inside ws_dev of a uint32 that the whole-frame kernel of mi_isp_pipeline12_reinhard sets to 1
+ * when one of its grid barriers timed out (a block of the launch never became resident, e.g. because the
+ * caller captured two frames onto parallel branches of one HIP graph).  The frame's output is then invalid.
+ * Stays 0 otherwise; hosts that want the check copy these 4 bytes back after synchronising. */
+size_t mi_isp_workspace_error_offset(int H, int W);
 
 /* ---- packed.py ------------------------------------------------------------------------ */
 /* decode12_kernel (packed.py:92-131): 3 bytes -> two 12-bit values; n_px must be even.

@@ -7,6 +7,8 @@
 #include "isp_tile.h"
 #include "isp_resize_tile.h"
 #include "isp_stream.h"
+#include "isp_mega.h"
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -264,6 +266,66 @@ static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, fl
   return 0;
 }
 
+// ---- the whole-frame kernel (isp_mega.h) --------------------------------------------------------------------------
+namespace mega { int blocks_per_cu(); }
+
+// Two whole-frame kernels must never share the chip: each needs every one of its blocks resident for its grid
+// barriers, and two half-resident grids would wait for each other (the kernel's bounded poll would turn that into an
+// error flag, not a hang - but the frame would be lost).  Launches on different streams of one device are therefore
+// chained through an event: the next launch waits for the previous one to finish.
+static struct {
+  std::mutex mu;
+  hipEvent_t done[16] = {};
+  int n_cus[16] = {};
+  int per_cu = -1;
+} g_mega;
+
+static bool mega_fits(const tile::Params& p, int work_dtype, const void* out, int out_dtype, strm::SArgs& a) {
+#ifdef MI_ISP_MEASURE
+  static const bool off = getenv("MI_ISP_PIPELINE") != nullptr;    // stream | cached: time the multi-pass chains
+  if (off) return false;
+#endif
+  if (work_dtype != MI_F16 || mi_dtype_size(out_dtype) > 2) return false;
+  if (!use_stream(p, work_dtype, out, out_dtype) || !p.vec_store) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  std::lock_guard<std::mutex> lock(g_mega.mu);
+  if (g_mega.per_cu < 0) g_mega.per_cu = mega::blocks_per_cu();
+  if (g_mega.n_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    g_mega.n_cus[dev] = n;
+  }
+  return g_mega.per_cu >= 2 && mega::geometry(p.H, p.W, g_mega.n_cus[dev], a);
+}
+
+static int pipeline_frame_mega(tile::Params p, strm::SArgs a, int pattern, float intensity, float* ws, hipStream_t s) {
+  p.fp = ws; p.partials = ws + FP_COUNT; p.part_stride = mi_partial_cap(p.H, p.W);
+  a.t = p;
+  a.n_px = (float)((int64_t)p.H * p.W); a.intensity = intensity; a.fp_w = ws; a.bounds_post = 2;
+  mega::MArgs m = {};
+  m.s = a;
+  m.sync = reinterpret_cast<unsigned*>(p.partials + (size_t)mega::SYNC_ROW * p.part_stride);
+  m.fpw = reinterpret_cast<unsigned*>(ws);
+  m.spin_limit = 100000;                                  // ~100 ms of polling before a wave gives up
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap != hipStreamCaptureStatusNone) return mega::launch(m, pattern, s);   // inside a graph: the capturer orders the frames
+  std::lock_guard<std::mutex> lock(g_mega.mu);
+  if (!g_mega.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_mega.done[dev], hipEventDisableTiming));
+  else MI_HIP(hipStreamWaitEvent(s, g_mega.done[dev], 0));
+  if (int rc = mega::launch(m, pattern, s)) return rc;
+  MI_HIP(hipEventRecord(g_mega.done[dev], s));
+  return 0;
+}
+
+extern "C" size_t mi_isp_workspace_error_offset(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  return (size_t)mega::FP_ERROR * sizeof(float);
+}
+
 // The same chain on the streaming kernels: every pass re-derives the demosaiced image from the packed frame
 // (18.9 MB, served by L2 / Infinity Cache after the first pass) instead of writing and re-reading a 6 B/px
 // intermediate; HBM sees the packed frame in and the output out.  Pass A (S_BOUNDS) also accumulates the statistics
@@ -331,6 +393,10 @@ static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, 
   if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, who)) return rc;
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
+  {
+    strm::SArgs ma = {};
+    if (mega_fits(p, work_dtype, out, out_dtype, ma)) return pipeline_frame_mega(p, ma, pattern, intensity, ws, s);
+  }
   if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && !force_cached())
     return pipeline_frame_stream(p, pattern, work_dtype, intensity, ws, -1, s);
   static const bool no_cached = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;

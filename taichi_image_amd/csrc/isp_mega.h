@@ -1,0 +1,559 @@
+// The fused config-2 chain (test/pipeline.py:26-32: decode12 -> bayer_to_rgb -> tonemap_reinhard) as ONE
+// persistent launch: the frame is demosaiced once, the f16 RGB image never leaves the chip, and the three
+// global dependencies of tonemap.py:146-154 (bounds -> statistics -> bounds of the mapped image -> final
+// map) are grid barriers inside the kernel instead of kernel boundaries.
+//
+// Why: every pass of this chain is bound by instruction throughput, not bandwidth, a kernel
+// boundary costs ~5 us of drain + launch + refill, and re-deriving the image per pass repeats the demosaic
+// (the largest single cost) three times.  Here HBM sees exactly the algorithmic bytes - the packed frame in,
+// the output out - and the demosaic runs once.
+//
+// Residency: a 4096 x 3072 frame is 75.5 MB of f16 RGB; the chip's register files hold 128 MB and its LDS
+// 40 MB.  Every wave (2048 of them, two per SIMD, all resident) keeps its 12 rows x 512 columns as packed
+// f16 pairs: 5 rows in LDS (3 KB per row and wave), 7 rows in 84 VGPRs.
+//
+//   phase A  streaming demosaic of the wave's rows (isp_stream.h machinery) -> bounds of the image, the
+//            statistics of tonemap.py:147-149 under the assumption that the bounds are exactly (0, 1), and
+//            the rounded f16 pixels into their resident slots
+//   barrier  -> bounds; when they are not (0, 1): phase B recomputes the statistics from the resident
+//            image (no memory traffic) and a second barrier follows
+//   phase C  Reinhard on the resident image -> bounds of the mapped image
+//   barrier
+//   phase D  Reinhard again, final normalisation, cast, wave-contiguous stores
+//
+// Grid barrier: one agent-scope atomic add per block on a counter of its own 128-byte line, after the
+// block's partial results have been stored write-through (sc1) and waited for; one wave per block polls
+// the counter with sc1 loads (MI355X_MICROARCH.md, cross-workgroup hand-off table, first row), folds all
+// blocks' partials with sc1 loads and hands the scalars to the other waves of its block through LDS.
+// Every block must be resident at once: the host launches at most 2 blocks per CU and refuses larger
+// frames (they take the multi-pass chain); a bounded poll turns a missing peer into an error flag in the
+// workspace instead of a hang.
+#pragma once
+#include "isp_stream.h"
+
+#pragma clang fp contract(off)
+
+namespace mega {
+
+using namespace strm;
+
+constexpr int ROWS = 12;             // rows per wave
+constexpr int NL = 5;                // of which live in LDS ...
+constexpr int NR = ROWS - NL;        // ... and in registers
+constexpr int ROW_U4 = 64 * 3;       // one f16 row of a wave: 64 lanes x 3 x 16 B
+
+// Sync words (uint32) in the workspace.  Atomic adds to ONE address serialise at the memory side (~40 ns each: 512
+// arrivals on one counter cost 15-20 us, measured), so every counter is kept as 32 shards, each on a 128-byte line
+// of its own; block b adds to shard b % 32 and a poller reads all 32 shards with one wave instruction.
+// Partial row 11 (unused by the passes, 4096 words) holds the shards of the three barriers and of the exit count;
+// two more words live in unused FrameParams slots.
+constexpr int SYNC_ROW = 11, SYNC_STRIDE = 32, SHARDS = 32;
+enum { SY_BAR0 = 0, SY_BAR1 = 1, SY_BAR2 = 2, SY_EXIT = 3 };
+// Phase B's statistics go to rows of their own: the speculative ones (rows 2..8) were read by every block at barrier 0,
+// and an sc1 load is served by the reader's L2 - a second read of a line another XCD has rewritten since may be stale.
+// Every partial row is therefore written once and read only after the barrier that follows its writing.
+constexpr int ROW_STATS_B = 12;
+constexpr int FP_EXIT2 = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
+MI_DEV unsigned* shard(unsigned* sync, int bar, int k) { return sync + (size_t)(bar * SHARDS + k) * SYNC_STRIDE; }
+
+struct MArgs {
+  SArgs s;
+  unsigned* sync;                    // partials + SYNC_ROW * part_stride
+  unsigned* fpw;                     // FrameParams as words (FP_EXIT2, FP_ERROR)
+  unsigned spin_limit;               // polls before a wave gives up (error flag, garbage frame, no hang)
+};
+
+MI_DEV float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+MI_DEV void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The block's contribution to a grid-wide reduction, then its arrival at barrier `bar`: every wave reduces in
+// registers and leaves its row in LDS; the wave that arrives last combines the rows in wave order, stores the block's
+// partial write-through, waits for the stores and signals with one atomic add.  No workgroup barrier.
+template <int NV>
+MI_DEV void block_reduce_signal(const float (&v)[NV], const int (&op)[NV], float (*red)[16], unsigned* arrived,
+                                float* partials, int stride, int block, int wave, int lane, unsigned* counter) {
+  float r[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) r[k] = op[k] == 0 ? wave_min(v[k]) : (op[k] == 1 ? wave_max(v[k]) : wave_sum(v[k]));
+  unsigned before = 0;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[wave][k] = r[k];
+    before = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  before = __builtin_amdgcn_readfirstlane(before);
+  if ((before & (WAVES - 1)) == WAVES - 1) {          // wave-uniform: this wave arrived last (the count runs on over the phases)
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float x = red[0][k];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) {
+        const float o = red[w][k];
+        x = op[k] == 0 ? fminf(x, o) : (op[k] == 1 ? fmaxf(x, o) : x + o);
+      }
+      mine = lane == k ? x : mine;
+    }
+    if (lane < NV) st_sc1(partials + (size_t)lane * stride + block, mine);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the block's shard
+  }
+}
+
+// four consecutive partials with one sc1 load (a buffer load the compiler can track: an asm load would hand its
+// destination registers back to the allocator while the data is still in flight).  aux 16 = sc1 on gfx950.
+MI_DEV float4 ld_sc1_x4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
+  return float4{__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y), __builtin_bit_cast(float, r.z),
+                __builtin_bit_cast(float, r.w)};
+}
+
+// Wait for barrier `bar` and derive the scalars of the next phase.  The first wave of the block to get here polls the
+// 32 counter shards (one sc1 load per lane), folds the partial rows of all blocks (identical arithmetic in every
+// block) and publishes the scalars in LDS; the other waves of the block wait for its LDS flag.
+// NROWS partial rows starting at `rows`: 2 = {min, max}; 7 = statistics; 9 = bounds followed by the speculative
+// statistics (folded together: the statistics are finalized only when the bounds turn out to be (0, 1)).
+template <int NROWS, int FIN>
+MI_DEV void barrier_fold(const MArgs& m, int bar, const float* rows, float* sh_fp, unsigned* ticket, unsigned* flag,
+                         int lane, unsigned* stamps = nullptr) {
+  const SArgs& a = m.s;
+  unsigned t = 0;
+  if (lane == 0) t = __hip_atomic_fetch_add(ticket + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  t = __builtin_amdgcn_readfirstlane(t);
+  if (t == 0) {
+    // ---- this wave folds for its block ----
+    unsigned spins = 0;
+    for (;;) {
+      unsigned c = lane < SHARDS ? __hip_atomic_load(shard(m.sync, bar, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      c = (unsigned)wave_sum((float)c);                // <= 2 * CUs: exact in fp32
+      if (c >= (unsigned)a.n_blocks) break;
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > m.spin_limit) {                   // a peer is not resident: give up loudly instead of hanging
+        if (lane == 0) __hip_atomic_store(m.fpw + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    if (stamps && lane == 0) stamps[0] = (unsigned)__builtin_readcyclecounter();
+    constexpr int NMM = NROWS == 9 ? 4 : 2;           // leading min / max rows (alternating)
+    float mm[NMM];
+    double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
+    // plain sc1 buffer loads (aux 16), not atomic loads: the compiler waits for an atomic load at once, and 72
+    // serialised round trips cost 24k cycles here (measured); these are issued together, one wait per round
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(rows), 0, (int)((size_t)NROWS * a.t.part_stride * sizeof(float)), 0x00020000);
+    for (int base = 0; base < a.n_blocks; base += 256) {      // four blocks per lane and round, all rows in flight together
+      float v[4][NROWS];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NROWS; ++k) {
+          const uint32_t off = i < a.n_blocks ? (uint32_t)((size_t)k * a.t.part_stride + i) * 4u : INVALID_OFF;
+          v[u][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, 16));
+          if (i >= a.n_blocks) v[u][k] = k < NMM ? ((k & 1) ? -__builtin_inff() : __builtin_inff()) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NROWS; ++k) {
+          if (k < NMM) mm[k] = (k & 1) ? fmaxf(mm[k], v[u][k]) : fminf(mm[k], v[u][k]);
+          else sum[k - NMM] += (double)v[u][k];
+        }
+    }
+    if (stamps && lane == 0) stamps[1] = (unsigned)__builtin_readcyclecounter();
+    double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NMM; ++k) tot[k] = (double)((k & 1) ? wave_max(mm[k]) : wave_min(mm[k]));
+    if (NROWS >= 7) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) tot[NMM + k] = wave_sum(sum[k]);
+    }
+    if (lane == 0) {
+      ew::FinArgs fa = {};
+      fa.fp = sh_fp; fa.n_px = a.n_px; fa.intensity = a.intensity; fa.la = a.t.la; fa.ca = a.t.ca;
+      fa.bounds_post = a.bounds_post;
+      if constexpr (NROWS == 9) {
+        ew::finalize_scalars<true>(ew::FIN_BOUNDS, fa, tot);
+        if (sh_fp[FP_LO] == 0.f && sh_fp[FP_INV] == 1.f) ew::finalize_scalars<true>(ew::FIN_STATS, fa, tot + 2);
+      } else {
+        ew::finalize_scalars<true>(FIN, fa, tot);
+      }
+      if (stamps) stamps[2] = (unsigned)__builtin_readcyclecounter();
+      __hip_atomic_store(flag + bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // block 0 leaves the frame's scalars in FrameParams, as the multi-pass chain does (callers may read them back)
+      if (blockIdx.x == 0 && a.fp_w) {
+        for (int i = 0; i <= FP_MAXOUT; ++i) a.fp_w[i] = sh_fp[i];
+      }
+    }
+  } else {
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > 64u * m.spin_limit) break;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// 24 f16 values of a resident row (12 packed registers) -> fp32
+MI_DEV void unpack_row(const uint32_t (&pk)[12], float (&t)[24]) {
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    half_t h[2];
+    __builtin_memcpy(h, &pk[j], 4);
+    t[2 * j] = (float)h[0]; t[2 * j + 1] = (float)h[1];
+  }
+}
+
+template <int PR, int PC>
+__global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
+  typedef half_t E;
+  const SArgs& a = m.s;
+  const Params& p = a.t;
+  __shared__ __attribute__((aligned(16))) uint4 xl[WAVES][NL][ROW_U4];   // resident rows 0..NL-1 of each wave; output staging
+  __shared__ float lut[4096];
+  __shared__ float red[WAVES][16];
+  __shared__ float sh_fp[FP_COUNT];
+  __shared__ unsigned arrived, ticket[4], flag[4];
+  if (threadIdx.x < 4) { ticket[threadIdx.x] = 0; flag[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) arrived = 0;
+  if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = 0.f;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blockIdx.x * WAVES + wave;
+  const bool wave_ok = g < a.n_waves;
+  const int by = g / a.bands_x, bx = g - by * a.bands_x;
+  const int c0 = bx * BAND + lane * 8;
+  const int r_begin = by * ROWS;
+  const int r_end = wave_ok ? (r_begin + ROWS < p.H ? r_begin + ROWS : p.H) : r_begin;
+  const bool col_ok = wave_ok && c0 < p.W;
+  const int active_lanes = !wave_ok ? 0 : (p.W - bx * BAND >= BAND ? 64 : (p.W - bx * BAND) / 8);
+
+  const uint32_t pitch = (uint32_t)p.W * 3 / 2;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
+  const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID_OFF;
+  const bool ext_ok = col_ok && ((lane == 0 && c0 > 0) || (lane == 63 && c0 + 8 < p.W));
+  const uint32_t ext_off = ext_ok ? (uint32_t)c0 * 3 / 2 + (lane == 0 ? -4 : 12) : INVALID_OFF;
+  auto load_row = [&](int r, uint32_t (&d)[4]) {
+    const uint32_t row_off = (r >= 0 && r < p.H && r < r_end + 2) ? (uint32_t)r * pitch : INVALID_OFF;     // scalar
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const u3 q = __builtin_amdgcn_raw_buffer_load_b96(rsrc, col_off + row_off, 0, 0);
+    d[0] = q.x; d[1] = q.y; d[2] = q.z;
+    d[3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ext_off + row_off, 0, 0);
+  };
+
+  MI_SSTAMP(0);
+  // ================================ phase A: demosaic once ================================
+  float wq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wq[i] = vgpr(wq_value(i));
+  WinRow win[6];
+  uint32_t raw[2][2][4];                              // row pairs in flight: two bodies ahead (~8k cycles) covers the latency
+  uint32_t xr[NR][12];                                // resident rows NL..ROWS-1 (packed f16 pairs)
+  {
+    uint32_t pro[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_row(r_begin - 2 + q, pro[q]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      load_row(r_begin + 2 + 2 * j, raw[j][0]);
+      load_row(r_begin + 3 + 2 * j, raw[j][1]);
+    }
+    for (int e = threadIdx.x; e < 4096; e += THREADS) lut[e] = tile::decode_scaled<E>((uint32_t)e, p.k_decode);
+    __syncthreads();                                  // table, tickets, flags, `arrived`: the kernel's only workgroup barrier
+#pragma unroll
+    for (int q = 0; q < 4; ++q) decode_row(pro[q], lut, lane, win[q]);
+  }
+  const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
+  const bool any_left = __builtin_amdgcn_ballot_w64(is_left) != 0, any_right = __builtin_amdgcn_ballot_w64(is_right) != 0;
+  const bool want_rgb = p.ca != 0.f;
+  float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  Stats2 st; st.init();
+
+  static_for<0, ROWS / 2>([&](auto ibc) {
+    constexpr int IB = decltype(ibc)::value, PH = IB % 3;
+    const int r = r_begin + 2 * IB;
+    decode_row(raw[IB % 2][0], lut, lane, win[(2 * PH + 4) % 6]);
+    decode_row(raw[IB % 2][1], lut, lane, win[(2 * PH + 5) % 6]);
+    if constexpr (IB + 2 < ROWS / 2) {
+      load_row(r + 6, raw[IB % 2][0]);
+      load_row(r + 7, raw[IB % 2][1]);
+    }
+    if (r < r_end) {                                  // wave-uniform
+      WinRow w6[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w6[k] = win[(2 * PH + k) % 6];
+      static_for<0, 2>([&](auto ic) {
+        constexpr int I = decltype(ic)::value, RR = 2 * IB + I;
+        const int row = r + I;
+        float v[24];
+        accumulate_row<PR, PC, I, true>(w6, wq, v);
+        if (row < 2 || row >= p.H - 2) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
+        else if (any_left || any_right) border_fix_cols<PR, PC, I>(v, is_left, is_right, any_left, any_right);
+        if (p.has_ccm) {                              // bayer.py:152-153, sequential fp32 dot
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float x = v[3 * k], y = v[3 * k + 1], z = v[3 * k + 2];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+              v[3 * k + ch] = (p.ccm[3 * ch] * x + p.ccm[3 * ch + 1] * y) + p.ccm[3 * ch + 2] * z;
+          }
+        }
+        // bounds: clamp and f16 rounding are monotone, applied once to the reduced values (bounds_post)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          vmin = fminf(vmin, fminf(v[3 * k], fminf(v[3 * k + 1], v[3 * k + 2])));
+          vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
+        }
+        uint32_t pk[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) pk[j] = tile::cvt_pk_f16_clamp01(v[2 * j], v[2 * j + 1]);
+        float t[24];
+        unpack_row(pk, t);
+        if (want_rgb) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) st.add2<true>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) st.add2<false>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+        }
+        // the pixels stay on the chip
+        if constexpr (RR < NL) {
+          uint4 mine[3];
+          __builtin_memcpy(mine, pk, sizeof(mine));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) xl[wave][RR][lane * 3 + j] = mine[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 12; ++j) xr[RR - NL][j] = pk[j];
+        }
+      });
+    }
+  });
+
+  MI_SSTAMP(1);
+  float* rows_bounds = p.partials + (size_t)ROW_BOUNDS * p.part_stride;
+  float* rows_stats = p.partials + (size_t)ROW_STATS_B * p.part_stride;
+  float* rows_bounds2 = p.partials + (size_t)ROW_BOUNDS2 * p.part_stride;
+  {
+    st.finish();
+    if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }
+    const float v9[9] = {vmin, vmax, st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
+    const int op[9] = {0, 1, 0, 1, 2, 2, 2, 2, 2};
+    block_reduce_signal<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane,
+                           shard(m.sync, SY_BAR0, blockIdx.x % SHARDS));
+  }
+
+  // the resident row RR as 24 fp32 values
+  auto resident = [&](auto rrc, float (&t)[24]) {
+    constexpr int RR = decltype(rrc)::value;
+    uint32_t pk[12];
+    if constexpr (RR < NL) {
+      uint4 mine[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) mine[j] = xl[wave][RR][lane * 3 + j];
+      __builtin_memcpy(pk, mine, sizeof(mine));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) pk[j] = xr[RR - NL][j];
+    }
+    unpack_row(pk, t);
+  };
+
+  // ================================ barrier 0: bounds (tonemap.py:146) ================================
+  MI_SSTAMP(2);
+#ifdef MI_STREAM_STAMPS
+  barrier_fold<9, ew::FIN_BOUNDS>(m, SY_BAR0, rows_bounds, sh_fp, ticket, flag, lane,
+                                  reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16 + 9);
+#else
+  barrier_fold<9, ew::FIN_BOUNDS>(m, SY_BAR0, rows_bounds, sh_fp, ticket, flag, lane);
+#endif
+  MI_SSTAMP(3);
+  const float lo_s = sh_fp[FP_LO], inv_s = sh_fp[FP_INV];
+  const bool unit = lo_s == 0.f && inv_s == 1.f;
+  // per-pixel operands live in VGPRs: a VALU instruction with an SGPR operand issues at half rate
+  const float lo = vgpr(lo_s), inv = vgpr(inv_s);
+  if (!unit) {
+    // ============================ phase B: the statistics for bounds other than (0, 1) ============================
+    st.init();
+    static_for<0, ROWS>([&](auto rrc) {
+      constexpr int RR = decltype(rrc)::value;
+      if (r_begin + RR < r_end) {
+        float t[24], n[24];
+        resident(rrc, t);
+#pragma unroll
+        for (int j = 0; j < 24; ++j) n[j] = norm01(t[j], lo, inv);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) st.add2<true>(n[3 * k], n[3 * k + 1], n[3 * k + 2], n[3 * k + 3], n[3 * k + 4], n[3 * k + 5]);
+      }
+    });
+    st.finish();
+    if (!col_ok) st.init();
+    const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
+    const int op[7] = {0, 1, 2, 2, 2, 2, 2};
+    block_reduce_signal<7>(v7, op, red, &arrived, rows_stats, p.part_stride, blockIdx.x, wave, lane,
+                           shard(m.sync, SY_BAR1, blockIdx.x % SHARDS));
+    barrier_fold<7, ew::FIN_STATS>(m, SY_BAR1, rows_stats, sh_fp, ticket, flag, lane);
+  }
+#if 0
+  else {
+    // the speculative statistics of phase A are the real ones: fold them (no further barrier: they were
+    // published together with the bounds)
+    barrier_fold<ew::FIN_STATS>(m, SY_BAR0, rows_stats, sh_fp, ticket + 1 - SY_BAR0, flag + 1 - SY_BAR0, lane);
+  }
+#endif
+  MI_SSTAMP(4);
+  ReinhardK rk;
+  const bool ca0 = p.ca == 0.f;
+  rk.la = vgpr(p.la); rk.ca = vgpr(p.ca);
+  rk.map_key = vgpr(sh_fp[FP_MAPKEY]); rk.ei = vgpr(sh_fp[FP_EI]);
+  rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
+
+  // Reinhard of one resident row (tonemap.py:120-131): q[24]
+  auto tone_row = [&](const float (&t)[24], float (&q)[24]) {
+    auto run = [&](auto unit_c, auto ca0_c) {
+      constexpr bool UNIT = decltype(unit_c)::value, CA0 = decltype(ca0_c)::value;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float x[3], o[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm01(t[3 * k + ch], lo, inv);
+        reinhard_px<CA0>(x, rk, o);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) q[3 * k + ch] = o[ch];
+      }
+    };
+    if (ca0) {
+      if (unit) run(std::true_type{}, std::true_type{});
+      else run(std::false_type{}, std::true_type{});
+    } else {
+      run(std::false_type{}, std::false_type{});
+    }
+  };
+
+  // ================================ phase C: bounds of the mapped image (tonemap.py:150-153) ================================
+  vmin = __builtin_inff(); vmax = -__builtin_inff();
+  static_for<0, ROWS>([&](auto rrc) {
+    constexpr int RR = decltype(rrc)::value;
+    if (r_begin + RR < r_end) {
+      float t[24], q[24];
+      resident(rrc, t);
+      tone_row(t, q);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        vmin = fminf(vmin, fminf(q[3 * k], fminf(q[3 * k + 1], q[3 * k + 2])));
+        vmax = fmaxf(vmax, fmaxf(q[3 * k], fmaxf(q[3 * k + 1], q[3 * k + 2])));
+      }
+    }
+  });
+  MI_SSTAMP(5);
+  {
+    if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); }
+    const float v2[2] = {vmin, vmax};
+    const int op[2] = {0, 1};
+    block_reduce_signal<2>(v2, op, red, &arrived, rows_bounds2, p.part_stride, blockIdx.x, wave, lane,
+                           shard(m.sync, SY_BAR2, blockIdx.x % SHARDS));
+  }
+  MI_SSTAMP(6);
+#ifdef MI_STREAM_STAMPS
+  barrier_fold<2, ew::FIN_BOUNDS2>(m, SY_BAR2, rows_bounds2, sh_fp, ticket, flag, lane,
+                                   reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16 + 12);
+#else
+  barrier_fold<2, ew::FIN_BOUNDS2>(m, SY_BAR2, rows_bounds2, sh_fp, ticket, flag, lane);
+#endif
+  MI_SSTAMP(7);
+  const float lo2 = vgpr(sh_fp[FP_LO2]), inv2 = vgpr(sh_fp[FP_INV2]);
+  const float out_scale = vgpr(p.out_scale);
+
+  // ================================ phase D: final map (tonemap.py:154) ================================
+  const int osz = (int)mi_dtype_size_dev(p.out_dtype);
+  const int unit_bytes = osz == 1 ? 8 : 16, units_per_lane = 24 * osz / unit_bytes;
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.dst, 0, (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz), 0x00020000);
+  uint32_t lane_off[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    lane_off[j] = (j * 64 + lane) < active_lanes * units_per_lane ? (uint32_t)(j * 64 + lane) * unit_bytes : INVALID_OFF;
+  const uint32_t out_pitch = (uint32_t)p.W * 3u * (uint32_t)osz, band_base = (uint32_t)bx * BAND * 3u * (uint32_t)osz;
+  static_for<0, ROWS>([&](auto rrc) {
+    constexpr int RR = decltype(rrc)::value;
+    if (r_begin + RR < r_end) {
+      float t[24], q[24];
+      resident(rrc, t);
+      tone_row(t, q);
+      linear_n<24>(q, lo2, inv2, p.gamma_inv, out_scale);
+      // staging: the LDS slot of a row that has been consumed (its own, or row 0's for the register rows)
+      uint4* stage = xl[wave][RR < NL ? RR : 0];
+      const uint32_t row_base = (uint32_t)(r_begin + RR) * out_pitch + band_base;
+      switch (p.out_dtype) {
+        case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, q); break;
+        case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, q); break;
+        default: {                                        // f16: pairs leave through v_cvt_pk_f16_f32 (half the conversions)
+          uint32_t pk[12];
+#pragma unroll
+          for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[j]) : "v"(q[2 * j]), "v"(q[2 * j + 1]));
+          uint4 mine[3];
+          __builtin_memcpy(mine, pk, sizeof(mine));
+          wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
+          break;
+        }
+      }
+    }
+  });
+
+  MI_SSTAMP(8);
+  // the last block to leave zeroes the sync words for the next launch on this workspace (a two-level count: the
+  // blocks of a shard, then the shards)
+  unsigned before = 0;
+  if (lane == 0) before = __hip_atomic_fetch_add(&arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  before = __builtin_amdgcn_readfirstlane(before);
+  if ((before & (WAVES - 1)) == WAVES - 1) {
+    const int k = blockIdx.x % SHARDS;
+    const unsigned in_shard = ((unsigned)a.n_blocks - (unsigned)k + SHARDS - 1) / SHARDS;
+    const unsigned used = (unsigned)a.n_blocks < (unsigned)SHARDS ? (unsigned)a.n_blocks : (unsigned)SHARDS;
+    unsigned last = 0;
+    if (lane == 0) {
+      if (__hip_atomic_fetch_add(shard(m.sync, SY_EXIT, k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1)
+        last = __hip_atomic_fetch_add(m.fpw + FP_EXIT2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1;
+    }
+    if (__builtin_amdgcn_readfirstlane(last)) {
+      for (int i = lane; i < 4 * SHARDS; i += 64)
+        __hip_atomic_store(m.sync + (size_t)i * SYNC_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(m.fpw + FP_EXIT2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+// The whole-frame kernel takes: f16 work dtype, 12-bit standard layout (strm::supported), outputs of 1 or 2 bytes per
+// element (the output row is staged in a 3 KB resident-row slot), and a frame whose waves (512 columns x 12 rows each)
+// are all resident at once: at most 2 blocks of 4 waves per CU.
+static inline bool geometry(int H, int W, int n_cus, SArgs& a) {
+  a.bands_x = (W + BAND - 1) / BAND;
+  a.rows_per_wave = ROWS;
+  const int bands_y = (H + ROWS - 1) / ROWS;
+  a.n_waves = a.bands_x * bands_y;
+  a.n_blocks = (a.n_waves + WAVES - 1) / WAVES;
+  return a.n_blocks <= 2 * n_cus;
+}
+
+int launch_rggb(const MArgs& m, hipStream_t stream);
+int launch_grbg(const MArgs& m, hipStream_t stream);
+int launch_gbrg(const MArgs& m, hipStream_t stream);
+int launch_bggr(const MArgs& m, hipStream_t stream);
+static inline int launch(const MArgs& m, int pattern, hipStream_t stream) {
+  switch (pattern) {
+    case MI_RGGB: return launch_rggb(m, stream);
+    case MI_GRBG: return launch_grbg(m, stream);
+    case MI_GBRG: return launch_gbrg(m, stream);
+    default: return launch_bggr(m, stream);
+  }
+}
+
+}  // namespace mega

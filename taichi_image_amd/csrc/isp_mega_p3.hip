@@ -1,0 +1,5 @@
+// Whole-frame kernel for the BGGR pattern: parity offsets (PR, PC) = (1, 1).
+#define PAT_PR 1
+#define PAT_PC 1
+#define PAT_FN launch_bggr
+#include "isp_mega_inst.inc"

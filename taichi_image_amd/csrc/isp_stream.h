@@ -51,7 +51,8 @@ enum Epi {
 //   S_BOUNDS / S_STORE_BOUNDS: rows 0,1 = min,max; rows 2..8 = gmin,gmax,slog2,sgray,s0,s1,s2 (speculative)
 //   S_STATS:                   rows 2..8 (overwrites the speculative ones)
 //   S_RH_MINMAX:               rows 9,10
-constexpr int ROW_BOUNDS = 0, ROW_STATS = 2, ROW_BOUNDS2 = 9, PART_ROWS = 12;
+constexpr int ROW_BOUNDS = 0, ROW_STATS = 2, ROW_BOUNDS2 = 9, PART_ROWS = 20;
+// (rows 11 and 12..18 belong to the whole-frame kernel, isp_mega.h: sync words, second statistics)
 
 struct SArgs {
   Params t;
@@ -512,13 +513,18 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   ReinhardK rk;
   rk.la = p.la; rk.ca = p.ca; rk.map_key = 1.f; rk.ei = 1.f; rk.mean3[0] = rk.mean3[1] = rk.mean3[2] = 0.f;
   if constexpr (EPI == S_STATS || EPI == S_RH_MINMAX || EPI == S_RH_STORE) { lo = sh_fp[FP_LO]; inv = sh_fp[FP_INV]; }
-  if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
-    rk.map_key = sh_fp[FP_MAPKEY]; rk.ei = sh_fp[FP_EI];
-    rk.mean3[0] = sh_fp[FP_MEAN3]; rk.mean3[1] = sh_fp[FP_MEAN3 + 1]; rk.mean3[2] = sh_fp[FP_MEAN3 + 2];
-  }
-  if constexpr (EPI == S_RH_STORE) { lo2 = sh_fp[FP_LO2]; inv2 = sh_fp[FP_INV2]; }
   // bounds exactly (0, 1): clamp((x - 0) * 1, 0, 1) is the identity on the clamped image
   const bool unit = lo == 0.f && inv == 1.f;
+  const bool ca0 = p.ca == 0.f;
+  // per-pixel operands live in VGPRs: a VALU instruction with an SGPR operand issues at half rate
+  lo = vgpr(lo); inv = vgpr(inv);
+  rk.la = vgpr(rk.la); rk.ca = vgpr(rk.ca);
+  if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
+    rk.map_key = vgpr(sh_fp[FP_MAPKEY]); rk.ei = vgpr(sh_fp[FP_EI]);
+    rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
+  }
+  if constexpr (EPI == S_RH_STORE) { lo2 = vgpr(sh_fp[FP_LO2]); inv2 = vgpr(sh_fp[FP_INV2]); }
+  const float out_scale = vgpr(p.out_scale);
   if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
     // block 0 publishes the pulled scalars for the passes after this one
     constexpr int FIN = EPI == S_RH_MINMAX ? (int)ew::FIN_STATS : (int)ew::FIN_BOUNDS2;
@@ -643,17 +649,25 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
             }
           }
           if constexpr (EPI == S_RH_STORE) {
-            linear_n<24>(o, lo2, inv2, p.gamma_inv, p.out_scale);                   // tonemap.py:154
+            linear_n<24>(o, lo2, inv2, p.gamma_inv, out_scale);                     // tonemap.py:154
             const uint32_t row_base = (uint32_t)row * out_pitch + band_base;
             switch (p.out_dtype) {
               case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, o); break;
               case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, o); break;
-              case MI_F16: wave_store_row_t<half_t>(drsrc, row_base, lane_off, lane, stage, o); break;
+              case MI_F16: {                                // pairs leave through v_cvt_pk_f16_f32 (half the conversions)
+                uint32_t pk2[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk2[j]) : "v"(o[2 * j]), "v"(o[2 * j + 1]));
+                uint4 mine[3];
+                __builtin_memcpy(mine, pk2, sizeof(mine));
+                wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
+                break;
+              }
               default: wave_store_row_t<float>(drsrc, row_base, lane_off, lane, stage, o); break;
             }
           }
         };
-        if (rk.ca == 0.f) {
+        if (ca0) {
           if (unit) tone(std::true_type{}, std::true_type{});
           else tone(std::false_type{}, std::true_type{});
         } else {
