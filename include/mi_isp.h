@@ -179,6 +179,20 @@ int mi_isp_pipeline12_reinhard(const uint8_t* packed_dev, void* out_dev, void* w
                                int ids_format, int pattern, const float* ccm9_host,
                                int work_dtype, int out_dtype, float gamma, float intensity,
                                float light_adapt, float color_adapt, void* ws_dev, void* stream);
+/* The same chain (test/pipeline.py:26-32) as ONE persistent launch (csrc/isp_mega.h): the frame is demosaiced once,
+ * the f16 RGB image stays in registers and LDS, the three global dependencies of tonemap.py:146-154 are grid
+ * barriers inside the kernel; HBM sees the packed frame in and the output out.  f16 work dtype; out_dtype u8 / u16 /
+ * f16; frames up to 2 x CUs x 4 waves of 512 x 12 pixels (4096 x 3072 on MI355X) - mi_isp_pipeline12_whole_frame_fits
+ * tells.  Results are within the tonemap tolerance of mi_isp_pipeline12_reinhard (same per-pixel functions).
+ * The kernel occupies the whole device: launches on different streams of one device are serialised by the library;
+ * do not capture two of them onto parallel branches of one HIP graph (the kernel would time out, set the error
+ * word of mi_isp_workspace_error_offset and leave an invalid frame - it never hangs). */
+int mi_isp_pipeline12_reinhard_whole_frame(const uint8_t* packed_dev, void* out_dev, int H, int W, int ids_format,
+                                           int pattern, const float* ccm9_host, int out_dtype, float gamma,
+                                           float intensity, float light_adapt, float color_adapt, void* ws_dev,
+                                           void* stream);
+int mi_isp_pipeline12_whole_frame_fits(int H, int W, int out_dtype);
+
 /* The same for n_frames independent frames, frame i on streams_host[i % n_streams]
  * (one frame per stream in flight); ws_dev holds n_frames consecutive workspaces;
  * work_images_host: one scratch image per frame, or NULL. */

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 for (H, W) in ((64, 512), (3072, 4096)):
     packed = synthetic.synthetic_packed12(1, H, W)
     frame = torch.from_numpy(packed).to(dev)
-    out = pipeline12_reinhard(frame)
+    out = pipeline12_reinhard(frame, whole_frame=True)
     torch.cuda.synchronize()
     ws = _native.workspace(H, W, dev)
     off = int(_native.lib().mi_isp_workspace_error_offset(H, W))
@@ -27,9 +27,9 @@ for (H, W) in ((64, 512), (3072, 4096)):
     err = assert_close(out.cpu().numpy(), ref, f"mega {H}x{W}")
     print("  parity ok, max err", err, flush=True)
 st = torch.cuda.current_stream(dev)
-for _ in range(5): pipeline12_reinhard(frame, out=out)
+for _ in range(5): pipeline12_reinhard(frame, out=out, whole_frame=True)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(st)
-for _ in range(50): pipeline12_reinhard(frame, out=out)
+for _ in range(50): pipeline12_reinhard(frame, out=out, whole_frame=True)
 e1.record(st); e1.synchronize()
 print(f"whole frame: {e0.elapsed_time(e1) * 1e3 / 50:.1f} us", flush=True)

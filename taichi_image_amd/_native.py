@@ -58,6 +58,9 @@ SIGNATURES = {
                                                  _P, POINTER(_P), c_int]),
     "mi_isp_pipeline12_pass": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_float,
                                        c_float, c_float, c_int, _P, _P]),
+    "mi_isp_pipeline12_reinhard_whole_frame": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_float, c_float,
+                                               c_float, c_float, _P, _P]),
+    "mi_isp_pipeline12_whole_frame_fits": (c_int, [c_int, c_int, c_int]),
     "mi_isp_workspace_error_offset": (ctypes.c_size_t, [c_int, c_int]),
     "mi_isp_profile_enable": (c_int, [c_int, c_int]),
     "mi_isp_profile_collect": (c_int, [POINTER(c_float), POINTER(c_int)]),   # float[4]

@@ -281,10 +281,6 @@ static struct {
 } g_mega;
 
 static bool mega_fits(const tile::Params& p, int work_dtype, const void* out, int out_dtype, strm::SArgs& a) {
-#ifdef MI_ISP_MEASURE
-  static const bool off = getenv("MI_ISP_PIPELINE") != nullptr;    // stream | cached: time the multi-pass chains
-  if (off) return false;
-#endif
   if (work_dtype != MI_F16 || mi_dtype_size(out_dtype) > 2) return false;
   if (!use_stream(p, work_dtype, out, out_dtype) || !p.vec_store) return false;
   int dev = 0;
@@ -382,10 +378,11 @@ static int pipeline_params(tile::Params& p, int H, int W, int ids_format, int pa
 
 // One frame: the cached variant when there is a place for the work-dtype image (the output itself when it has the
 // work dtype, else `work_image`), the recompute variant otherwise.
+// whole_frame: 0 = the multi-pass chain, 1 = the single-launch whole-frame kernel (an error when the frame does not fit)
 static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, int H, int W, int ids_format,
                             int pattern, const float* ccm9, int work_dtype, int out_dtype, float gamma,
                             float intensity, float light_adapt, float color_adapt, float* ws, hipStream_t s,
-                            const char* who) {
+                            const char* who, int whole_frame = 0) {
   tile::Params p = {};
   if (int rc = pipeline_params(p, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma, light_adapt,
                                color_adapt))
@@ -393,9 +390,13 @@ static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, 
   if (int rc = packed_params(p, packed, H, W, 12, ids_format, work_dtype, who)) return rc;
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
-  {
+  if (whole_frame) {
     strm::SArgs ma = {};
-    if (mega_fits(p, work_dtype, out, out_dtype, ma)) return pipeline_frame_mega(p, ma, pattern, intensity, ws, s);
+    MI_REQUIRE(mega_fits(p, work_dtype, out, out_dtype, ma),
+               "%s: the whole-frame kernel takes f16 work dtype, u8 / u16 / f16 outputs, the standard 12-bit layout with "
+               "W %% 8 == 0 and 16-byte aligned buffers, and at most 2 x CUs x 4 waves of 512 x 12 pixels (4096 x 3072 on "
+               "MI355X); use mi_isp_pipeline12_reinhard for this frame", who);
+    return pipeline_frame_mega(p, ma, pattern, intensity, ws, s);
   }
   if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && !force_cached())
     return pipeline_frame_stream(p, pattern, work_dtype, intensity, ws, -1, s);
@@ -416,6 +417,23 @@ extern "C" int mi_isp_pipeline12_reinhard(const uint8_t* packed, void* out, void
   return pipeline12_frame(packed, out, work_image, H, W, ids_format, pattern, ccm9, work_dtype, out_dtype, gamma,
                           intensity, light_adapt, color_adapt, static_cast<float*>(ws), (hipStream_t)stream,
                           "pipeline12_reinhard");
+}
+
+extern "C" int mi_isp_pipeline12_reinhard_whole_frame(const uint8_t* packed, void* out, int H, int W, int ids_format,
+                                                      int pattern, const float* ccm9, int out_dtype, float gamma,
+                                                      float intensity, float light_adapt, float color_adapt, void* ws,
+                                                      void* stream) {
+  MI_REQUIRE(out && ws, "pipeline12_reinhard_whole_frame: null pointer");
+  return pipeline12_frame(packed, out, nullptr, H, W, ids_format, pattern, ccm9, MI_F16, out_dtype, gamma, intensity,
+                          light_adapt, color_adapt, static_cast<float*>(ws), (hipStream_t)stream,
+                          "pipeline12_reinhard_whole_frame", 1);
+}
+
+extern "C" int mi_isp_pipeline12_whole_frame_fits(int H, int W, int out_dtype) {
+  tile::Params p = {};
+  p.H = H; p.W = W; p.src_kind = tile::SRC_PACKED12; p.src_fast = 1; p.in_scale = 1.f; p.vec_store = 1;
+  strm::SArgs a = {};
+  return H > 0 && W > 0 && H % 2 == 0 && mi_valid_dtype(out_dtype) && mega_fits(p, MI_F16, nullptr, out_dtype, a) ? 1 : 0;
 }
 
 extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, void* const* out,

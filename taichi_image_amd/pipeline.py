@@ -26,14 +26,28 @@ def _check_packed(packed):
     return H, W
 
 
+def whole_frame_fits(H, W, dtype=types.f16):
+    """Can pipeline12_reinhard(..., whole_frame=True) take an H x W frame with this output dtype?"""
+    return bool(_native.lib().mi_isp_pipeline12_whole_frame_fits(int(H), int(W), types.as_dtype(dtype).code))
+
+
 def pipeline12_reinhard(packed, pattern=BayerPattern.RGGB, ids_format=False, correct_colors=None,
                         work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0, light_adapt=1.0,
-                        color_adapt=0.0, out=None):
+                        color_adapt=0.0, out=None, whole_frame=False):
+    """whole_frame=True: the single-launch kernel (csrc/isp_mega.h; f16 work dtype, u8 / u16 / f16 output, frames up
+    to 4096 x 3072 on MI355X) instead of the multi-pass chain; same results within the tonemap tolerance."""
     H, W = _check_packed(packed)
     work, odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
     if out is None:
         out = torch.empty((H, W, 3), dtype=odt.torch, device=packed.device)
     ws = _native.workspace(H, W, packed.device)
+    if whole_frame:
+        assert work.code == types.f16.code, "the whole-frame kernel works in f16"
+        _native.check(_native.lib().mi_isp_pipeline12_reinhard_whole_frame(
+            packed.data_ptr(), out.data_ptr(), H, W, int(bool(ids_format)), pattern.value,
+            _native.ccm_arg(correct_colors), odt.code, float(gamma), float(intensity), float(light_adapt),
+            float(color_adapt), ws.data_ptr(), _native.stream_ptr(packed.device)))
+        return out
     # an output dtype other than the work dtype: scratch for the work-dtype image between the passes (the
     # caching allocator makes this cheap; without it the library re-derives the image in every pass)
     work_image = None if odt.code == work.code else torch.empty((H, W, 3), dtype=work.torch, device=packed.device)

@@ -143,3 +143,79 @@ def test_pipeline12_4k_non_unit_bounds(ti, dev, scenes, out):
     assert rgb.min() > 0.0 and rgb.max() < 1.0, "the frame must not touch the clamp"
     got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=getattr(ti.types, out)).cpu().numpy()
     assert_close(got, ref, f"pipeline12 4K non-unit bounds -> {out}")
+
+
+# ---- the whole-frame kernel (csrc/isp_mega.h): one persistent launch with grid barriers ------------------------
+def _error_word(ti, H, W, dev):
+    from taichi_image_amd import _native
+    ws = _native.workspace(H, W, dev)
+    off = int(_native.lib().mi_isp_workspace_error_offset(H, W))
+    return int(ws[off:off + 4].view(torch.int32).item())
+
+
+@pytest.mark.parametrize("shape", [(4, 8), (12, 512), (26, 520), (64, 512), (130, 1544), (3072, 4096)])
+@pytest.mark.parametrize("out", ["f16", "u8"])
+def test_whole_frame_kernel_matches_c_oracle(ti, dev, rng, shape, out):
+    """Every frame shape class: one wave, partial bands, partial last row band, partial block, the full chip."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard, whole_frame_fits
+    H, W = shape
+    assert whole_frame_fits(H, W, getattr(ti.types, out))
+    packed = natural_packed12(rng, H, W) if H < 3072 else packed_from(mosaic_rggb(synthetic_scene(7)))
+    ref = c_oracle.pipeline12_reinhard(packed, work="f16", out=out)
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=getattr(ti.types, out), whole_frame=True)
+    torch.cuda.synchronize()
+    assert _error_word(ti, H, W, dev) == 0, "a grid barrier of the whole-frame kernel timed out"
+    assert_close(got.cpu().numpy(), ref, f"whole-frame {H}x{W} -> {out}")
+
+
+@pytest.mark.parametrize("kw", [dict(gamma=0.6, intensity=1.5, light_adapt=0.7, color_adapt=0.4),
+                                dict(gamma=2.2, intensity=0.5, light_adapt=1.0, color_adapt=0.0)])
+def test_whole_frame_kernel_parameters_patterns_and_bounds(ti, dev, scenes, kw):
+    """Non-default Reinhard parameters, every CFA pattern, a colour matrix, and a frame whose bounds are not (0, 1)
+    (the in-kernel statistics fallback, phase B) at full size; repeated launches on one workspace."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    for p in range(4):
+        packed = natural_packed12(np.random.default_rng(5 + p), 96, 1024, pattern=p)
+        ccm = O.isp_color_matrix(True, O.DEFAULT_WB, O.DEFAULT_CC) if p == 2 else None
+        ref = O.pipeline12_reinhard(packed, pattern=p, correct_colors=ccm, out="f16", **kw)
+        got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), pattern=ti.BayerPattern(p), correct_colors=ccm,
+                                  whole_frame=True, **kw)
+        assert_close(got.cpu().numpy(), ref, f"whole-frame pattern {p} {kw}")
+    packed = packed_from(scenes[2], 0.7, 0.1)                      # bounds inside (0, 1)
+    ref = c_oracle.pipeline12_reinhard(packed, work="f16", out="f16", **kw)
+    frame = torch.from_numpy(packed).to(dev)
+    for rep in range(3):                                           # the kernel re-arms its own barrier counters
+        got = pipeline12_reinhard(frame, whole_frame=True, **kw)
+        torch.cuda.synchronize()
+        assert _error_word(ti, 3072, 4096, dev) == 0
+        assert_close(got.cpu().numpy(), ref, f"whole-frame 4K non-unit bounds {kw} rep {rep}")
+
+
+def test_whole_frame_kernel_streams_are_serialised(ti, dev, scenes):
+    """Launches from two streams: the library chains them (two whole-frame grids must never share the chip)."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    packed = [packed_from(scenes[k]) for k in range(2)]
+    frames = [torch.from_numpy(p).to(dev) for p in packed]
+    refs = [c_oracle.pipeline12_reinhard(p, work="f16", out="f16") for p in packed]
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    outs = [None, None]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs[k] = pipeline12_reinhard(frames[k], whole_frame=True)
+    torch.cuda.synchronize()
+    from taichi_image_amd import _native
+    for k in range(2):
+        with torch.cuda.stream(streams[k]):
+            assert _error_word(ti, 3072, 4096, dev) == 0
+        assert_close(outs[k].cpu().numpy(), refs[k], f"stream {k}")
+
+
+def test_whole_frame_kernel_refuses_what_it_cannot_hold(ti, dev):
+    from taichi_image_amd.pipeline import pipeline12_reinhard, whole_frame_fits
+    assert not whole_frame_fits(3072 + 12, 4096)            # one row band more than the chip holds
+    assert not whole_frame_fits(64, 512, ti.types.f32)      # 4-byte outputs do not fit the staging slot
+    big = torch.zeros((3084, 6144), dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="whole-frame"):
+        pipeline12_reinhard(big, whole_frame=True)
