@@ -7,19 +7,26 @@
 A "step" is one pass of the hot path over one batch of synthetic frames: BASELINE config 2,
 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap -> f16 RGB (the stateless chain of the
 reference's test/pipeline.py:26-32), `--frames` frames per rank per step, one frame per HIP
-stream in flight.  Frames are independent, so N ranks shard the batch with no data-path
-collective ("scaling": "weak": per-GPU work is fixed).  Inputs are resident in HBM before the
-timed region; value = total megapixels (sensor pixels) of all ranks / max-over-ranks wall time.
+stream in flight, the step replayed as a HIP graph captured inside the library
+(mi_isp_pipeline12_graph_create).  Frames are independent, so N ranks shard the batch with no
+data-path collective ("scaling": "weak": per-GPU work is fixed).  Inputs are resident in HBM before
+the timed region; value = total megapixels (sensor pixels) of all ranks / max-over-ranks wall time.
 
 One JSON line is printed by rank 0; besides the driver's contract keys it carries
-  roofline     : the dominant kernel (final map + store pass) timed with events on its stream
-  cpu_baseline : the CPU oracle (a port, NOT the reference's Taichi CPU backend, which cannot be
-                 installed here) timed on this box's host cores, rank 0 at N=1 only
-  kernels_us   : average duration of each of the four data passes
+  roofline        : the dominant kernel (the pass that reads the packed frame and writes the output: final map +
+                    store) timed with HIP events on the stream it runs on, over launch-by-launch steps interleaved in
+                    the timed region
+  cpu_baseline    : the CPU oracle (a port, NOT the reference's Taichi CPU backend, which cannot be
+                    installed here) timed on this box's host cores, rank 0 at N=1 only
+  kernels_us_*    : average duration of each data pass, in situ and isolated
+  other_workloads : (N=1) driver-run numbers of the other single-GPU configurations - config 3, config 2 with u8
+                    output, config 2 on frames whose bounds are not (0, 1) (no data-dependent shortcut), and
+                    config 2 through the single-launch whole-frame kernel
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -38,15 +45,19 @@ BYTES_IN = H * W * 3 // 2            # packed-12 frame
 BYTES_OUT_F16 = H * W * 3 * 2        # f16 RGB frame
 ALG_BYTES = BYTES_IN + BYTES_OUT_F16  # 94 371 840 B / frame = 7.5 B/px
 HBM_PEAK_GBS = 8000.0                # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# the four data passes of the f16 -> f16 pipeline ("cached" variant, csrc/isp_api.hip)
-PASS_NAMES = ["pass0: tile_kernel<f16,RGGB,EPI_STORE_MINMAX> (unpack + demosaic -> f16 RGB + bounds)",
-              "pass1: rgb_pass_kernel<f16,f16,PM_STATS> (metering sums)",
-              "pass2: rgb_pass_kernel<f16,f16,PM_RH_MINMAX> (Reinhard bounds)",
-              "pass3: rgb_pass_kernel<f16,f16,PM_RH_STORE> (final map, in place)"]
+METRIC = "megapixels/sec end-to-end ISP, 4096x3072 RGGB12; % HBM roofline"
+# the data passes of the f16 -> f16 chain on the streaming kernels (csrc/isp_stream.h, csrc/isp_api.hip:
+# pipeline_frame_stream): every pass re-derives the demosaiced image from the packed frame
+PASS_NAMES = ["pass0: stream_kernel<f16,RGGB,S_BOUNDS> (unpack + demosaic -> bounds + speculative statistics)",
+              "pass1: stream_kernel<f16,RGGB,S_STATS> (statistics for bounds other than (0, 1); returns at once otherwise)",
+              "pass2: stream_kernel<f16,RGGB,S_RH_MINMAX> (unpack + demosaic + Reinhard -> bounds of the mapped image)",
+              "pass3: stream_kernel<f16,RGGB,S_RH_STORE> (unpack + demosaic + Reinhard + final map -> f16 RGB)"]
+# algorithmic bytes per launch: passes 0-2 read the packed frame, pass 3 reads it and writes the output
+PASS_BYTES = [BYTES_IN, BYTES_IN, BYTES_IN, BYTES_IN + BYTES_OUT_F16]
 
 
-def time_passes(frame, out, ws_ptr, device, reps=10):
-    """Average duration (us) of each data pass, events on the stream the kernels run on."""
+def time_passes(frame, out, ws_ptr, device, reps=20):
+    """Average duration (us) of each data pass in isolation, events on the stream the kernels run on."""
     from taichi_image_amd import _native, types
     L = _native.lib()
     stream = torch.cuda.current_stream(device)
@@ -56,7 +67,7 @@ def time_passes(frame, out, ws_ptr, device, reps=10):
             _native.check(L.mi_isp_pipeline12_pass(frame.data_ptr(), out.data_ptr(), H, W, 0, 0, None,
                                                    types.f16.code, types.f16.code, 1.0, 1.0, 0.0, p, ws_ptr,
                                                    stream.cuda_stream))
-        for _ in range(2):
+        for _ in range(3):
             launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -69,21 +80,23 @@ def time_passes(frame, out, ws_ptr, device, reps=10):
 
 
 def cpu_baseline(packed_frame: np.ndarray):
-    """The CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+    """The CPU oracle on a bounded sample of the same workload (rank 0, N=1 only): median of 10 after 3 warm-ups."""
     ncores = os.cpu_count() or 1
     try:
         from oracle import c_oracle
         if c_oracle.available():
             # the GPU box gives one GPU a share of 16 host cores; stay inside it
             c_oracle.set_threads(min(ncores, 16))
-            reps, times = 3, []
-            for _ in range(reps):
+            warm, reps, times = 3, 10, []
+            for i in range(warm + reps):
                 t0 = time.perf_counter()
                 c_oracle.pipeline12_reinhard(packed_frame)
-                times.append(time.perf_counter() - t0)
+                if i >= warm:
+                    times.append(time.perf_counter() - t0)
             t = float(np.median(times))
             return {"value": round(MP / t, 3), "unit": "MP/s", "cores": c_oracle.threads(), "kind": "port",
-                    "sample": f"1 full 4096x3072 frame, median of {reps}, C/OpenMP restatement (oracle/isp_oracle.c)"}
+                    "sample": f"1 full 4096x3072 frame per run, median of {reps} runs after {warm} warm-ups, "
+                              f"C/OpenMP restatement (oracle/isp_oracle.c), host has {ncores} hardware threads"}
     except ImportError:
         pass
     from oracle import isp_oracle as O
@@ -102,19 +115,35 @@ def reduce_device(device):
     return torch.device("cpu") if os.environ.get("MI_ISP_BENCH_BACKEND", "nccl") == "gloo" else device
 
 
+def timed(fn, steps, warmup, device, barrier=None):
+    """`steps` calls of fn bracketed by synchronisation (and the ranks' barrier); seconds."""
+    sync = barrier or (lambda: torch.cuda.synchronize(device))
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return time.perf_counter() - t0
+
+
+def isp_step_fn(frames_dev, device, process_group=None):
+    import taichi_image_amd as ti
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, resize_width=1920, device=device,
+                      process_group=process_group)
+    return lambda: isp.tonemap_reinhard([isp.load_packed12(f) for f in frames_dev], gamma=0.6)
+
+
 def isp_workload(args, rank, world, device):
     """Configs 3 / 5: the stateful Camera16 chain on `--frames` cameras per rank per step."""
     import torch.distributed as dist
-    import taichi_image_amd as ti
     from taichi_image_amd import synthetic
     shared = args.workload == "isp-shared-stats"
     group = dist.group.WORLD if (shared and world > 1) else None
-    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, resize_width=1920, device=device, process_group=group)
     host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(min(4, args.frames))]
     frames = [torch.from_numpy(host[i % len(host)]).to(device) for i in range(args.frames)]
-
-    def step():
-        return isp.tonemap_reinhard([isp.load_packed12(f) for f in frames], gamma=0.6)
+    step = isp_step_fn(frames, device, group)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -122,14 +151,7 @@ def isp_workload(args, rank, world, device):
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(step, args.steps, args.warmup, device, barrier)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -137,7 +159,7 @@ def isp_workload(args, rank, world, device):
     if rank == 0:
         out_bytes = 1440 * 1920 * 3
         print(json.dumps({
-            "metric": "megapixels/sec end-to-end ISP, 4096x3072 RGGB12; % HBM roofline",
+            "metric": METRIC,
             "value": round(world * args.frames * args.steps * MP / elapsed, 1), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -154,23 +176,66 @@ def isp_workload(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def other_workloads(frames, host, device, frames_per_step):
+    """Short driver-visible runs of the other single-GPU configurations (rank 0, N=1)."""
+    from taichi_image_amd import types
+    from taichi_image_amd.pipeline import BatchPipeline, whole_frame_fits
+    from taichi_image_amd.synthetic import pack12
+    res = {}
+
+    def run_batch(name, fr, alg_bytes, steps=150, **kw):
+        bp = BatchPipeline(len(fr), H, W, device, use_graph=True, **kw)
+        bp.prepare(fr)
+        el = timed(lambda: bp(fr), steps, 10, device)
+        us = el / (steps * len(fr)) * 1e6
+        res[name] = {"MP_per_s": round(MP / us * 1e6, 1), "us_per_frame": round(us, 2),
+                     "frac_of_hbm_roofline": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_frame": alg_bytes, "frames_per_step": len(fr), "steps": steps}
+        del bp
+
+    # config 2 with the u8 output of the ISP semantics (SURVEY 8(d): 4.5 B/px)
+    run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, dtype=types.u8, n_streams=2)
+    # config 2 on frames whose demosaiced bounds are NOT (0, 1): the statistics pass runs in full (no data-dependent
+    # shortcut); scene scaled into [0.1, 0.8]
+    def rescale(p):
+        b = p.reshape(H, -1, 3).astype(np.uint32)
+        v = np.stack([b[..., 0] | ((b[..., 1] & 0xF) << 8), (b[..., 1] >> 4) | (b[..., 2] << 4)], -1).reshape(H, W)
+        v = np.rint(v * 0.7 + 0.1 * 4095).astype(np.uint16)
+        return pack12(v)
+    nonunit = [torch.from_numpy(rescale(host[i % len(host)])).to(device) for i in range(len(frames))]
+    run_batch("config2_bounds_not_unit", nonunit, ALG_BYTES, n_streams=2)
+    # config 2 through the single-launch whole-frame kernel (csrc/isp_mega.h), frames one after the other
+    if whole_frame_fits(H, W, types.f16):
+        run_batch("config2_whole_frame_kernel", frames, ALG_BYTES, whole_frame=True)
+        run_batch("config2_whole_frame_kernel_bounds_not_unit", nonunit, ALG_BYTES, whole_frame=True)
+    # config 3: Camera16(resize_width=1920): load_packed12 x frames + tonemap_reinhard(gamma=0.6) -> u8 1920x1440
+    step = isp_step_fn(frames[:6], device)
+    steps = 100
+    el = timed(step, steps, 10, device)
+    us = el / (steps * 6) * 1e6
+    alg3 = BYTES_IN + 1440 * 1920 * 3
+    res["config3_camera16_resize1920"] = {"MP_per_s": round(MP / us * 1e6, 1), "us_per_frame": round(us, 2),
+                                          "frac_of_hbm_roofline": round(alg3 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "algorithmic_bytes_per_frame": alg3, "frames_per_step": 6, "steps": steps}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000, help="steps of the timed region (8 frames each: ~0.6 s)")
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--frames", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per rank (frames in flight)")
-    ap.add_argument("--profile-every", type=int, default=5,
-                    help="HIP events around the passes of every n-th frame of the timed region")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as a captured HIP graph (+4-6 %% throughput, DESIGN.md 7).  Not the default: "
-                         "kernels inside a graph cannot be timed with events, so the per-pass durations would come "
-                         "from the few steps issued launch by launch (--eager-every) and stop agreeing with rocprofv3")
-    ap.add_argument("--eager-every", type=int, default=10,
-                    help="with --graph: every n-th step of the timed region is issued launch by launch so that "
-                         "the per-pass events (--profile-every) can be recorded")
+    ap.add_argument("--profile-every", type=int, default=2,
+                    help="HIP events around the passes of every n-th frame of the launch-by-launch steps")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="issue every step launch by launch instead of replaying the captured HIP graph")
+    ap.add_argument("--eager-every", type=int, default=25,
+                    help="every n-th step of the timed region is issued launch by launch so that the per-pass "
+                         "events (--profile-every) can be recorded (events inside a graph cannot be timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2", "isp", "isp-shared-stats"],
                     help="config2 (default, the BASELINE metric) | isp: Camera16(resize_width=1920) load_packed12 + "
                          "tonemap_reinhard(gamma=0.6), config 3 | isp-shared-stats: the same with the rolling metering "
@@ -199,13 +264,16 @@ def main():
     from taichi_image_amd.pipeline import BatchPipeline
 
     if args.workload != "config2":
+        if args.steps == 1000:
+            args.steps = 200
         return isp_workload(args, rank, world, device)
 
     # distinct synthetic frames per rank (seeds 1234 + k); 4 distinct, cycled
     n_distinct = min(4, args.frames)
     host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(n_distinct)]
     frames = [torch.from_numpy(host[i % n_distinct]).to(device) for i in range(args.frames)]
-    bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams, use_graph=args.graph)
+    use_graph = not args.no_graph
+    bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams, use_graph=use_graph)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -214,16 +282,16 @@ def main():
         torch.cuda.synchronize(device)
 
     from taichi_image_amd import _native
-    import ctypes
     bp.prepare(frames)                    # set-up (module load, graph capture), not a step
     for _ in range(args.warmup):
         bp(frames)
     barrier()
-    # events around every launch of the dominant kernel inside the timed region (rank 0's line)
-    _native.check(_native.lib().mi_isp_profile_enable(args.frames * args.steps, args.profile_every))
+    # events around every data pass of the launch-by-launch steps inside the timed region (rank 0's line)
+    n_eager = (args.steps + args.eager_every - 1) // max(1, args.eager_every) if use_graph else args.steps
+    _native.check(_native.lib().mi_isp_profile_enable(args.frames * n_eager, args.profile_every))
     t0 = time.perf_counter()
     for step in range(args.steps):
-        bp(frames, eager=(not args.graph) or (step % max(1, args.eager_every) == 0))
+        bp(frames, eager=(not use_graph) or (step % max(1, args.eager_every) == 0))
     barrier()
     elapsed = time.perf_counter() - t0
     live_us, live_n = (ctypes.c_float * 4)(), ctypes.c_int(0)
@@ -240,42 +308,52 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         passes = time_passes(frames[0], bp.outputs[0], bp.ws.data_ptr(), device)
         live = [float(v) for v in live_us]            # in-situ averages over the timed region
-        dom = int(np.argmax(live))                    # the dominant kernel = the longest data pass
+        # the dominant kernel: the pass that carries the frame's algorithmic bytes - it reads the packed frame and
+        # writes the output (passes 0-2 only re-read the 18.9 MB packed frame and leave a few hundred bytes)
+        dom = 3
         dom_us = live[dom]
-        # algorithmic bytes per launch of each pass: pass 0 reads the packed frame and writes
-        # the f16 image, passes 1-2 read it, pass 3 reads and rewrites it
-        pass_bytes = [BYTES_IN + BYTES_OUT_F16, BYTES_OUT_F16, BYTES_OUT_F16, 2 * BYTES_OUT_F16]
-        dom_bytes = pass_bytes[dom]
+        dom_bytes = PASS_BYTES[dom]
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        traffic = None
+        # HBM-side bytes of the dominant kernel: NOT measured by this run - cited from the committed PMC profile
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, scripts/profile_round.sh)
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath))["kernels"][f"pass{dom}"]["hbm_bytes"]
+                doc = json.load(open(tpath))
+                traffic = doc["kernels"][f"pass{dom}"]["hbm_bytes"]
+                traffic_src = "profile-cited, not measured in this run: profiles/traffic_latest.json (" + doc.get("tag", "?") + ")"
             except Exception:
                 traffic = None
         line = {
-            "metric": "megapixels/sec end-to-end ISP, 4096x3072 RGGB12; % HBM roofline",
+            "metric": METRIC,
             "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config 2: 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap (stateless, "
                                    "gamma 1) -> f16 RGB", "frames_per_rank_per_step": args.frames,
                        "streams_per_rank": args.streams, "work_dtype": "f16",
-                       "launch": (f"HIP graph replay of the step; every {args.eager_every}th step launch by launch for the per-pass events"
-                                  if args.graph else "launch by launch"), "sharding": f"frames x{world}, no collective"},
+                       "launch": (f"HIP graph replay of the step (captured inside the library); every {args.eager_every}th "
+                                  "step launch by launch for the per-pass events" if use_graph else "launch by launch"),
+                       "sharding": f"frames x{world}, no collective"},
             "us_per_frame": round(elapsed / (args.frames * args.steps) * 1e6, 2),
+            "timed_region_s": round(elapsed, 3),
             "pipeline_frac_of_hbm_roofline": round(ALG_BYTES * world * args.frames * args.steps / elapsed / 1e9
                                                    / (HBM_PEAK_GBS * world), 4),
             "roofline": {"bound": "hbm", "kernel": PASS_NAMES[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_us, 2),
                          "launches_timed": int(live_n.value), "isolated_launch_us": round(passes[dom], 2),
-                         "isolated_frac": round(dom_bytes / (passes[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "isolated_frac": round(dom_bytes / (passes[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "every pass of this chain is bound by instruction throughput (fetch + VALU issue), "
+                                 "not by bandwidth: DESIGN.md 5"},
             "kernels_us_live": {f"pass{k}": round(live[k], 2) for k in range(4)},
             "kernels_us_isolated": {f"pass{k}": round(passes[k], 2) for k in range(4)},
         }
+        if world == 1 and not args.no_other_workloads:
+            del bp
+            line["other_workloads"] = other_workloads(frames, host, device, args.frames)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host[0])
         else:

@@ -205,6 +205,19 @@ int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed_host, void* co
                                      int n_streams);
 
 
+/* A batch of the chain above as a HIP graph (what hipStreamBeginCapture around mi_isp_pipeline12_reinhard_batch gives,
+ * done inside the library): create() captures the step for the given buffers - fork to n_streams internal streams,
+ * frame i on stream i % n_streams, join - and instantiates it; launch() replays it on `stream` (stream-ordered like any
+ * other call; a replay has no launch gaps between the dependent kernels of a stream); destroy() frees it.  The buffers
+ * must keep their addresses for the lifetime of the graph; ws_dev holds n_frames workspaces (zero-filled once).
+ * whole_frame != 0: every frame through mi_isp_pipeline12_reinhard_whole_frame, one after the other. */
+int mi_isp_pipeline12_graph_create(const uint8_t* const* packed_dev, void* const* out_dev, void* const* work_images_dev,
+                                   int n_frames, int H, int W, int ids_format, int pattern, const float* ccm9_host,
+                                   int work_dtype, int out_dtype, float gamma, float intensity, float light_adapt,
+                                   float color_adapt, void* ws_dev, int n_streams, int whole_frame, void** handle);
+int mi_isp_pipeline12_graph_launch(void* handle, void* stream);
+int mi_isp_pipeline12_graph_destroy(void* handle);
+
 /* ---- measurement aid ----------------------------------------------------------------------- */
 /* Launches ONE data pass (0 = demosaic + bounds, 1 = metering sums, 2 = Reinhard bounds, 3 = final
  * map + store) of mi_isp_pipeline12_reinhard, so that bench.py can time each kernel in isolation with

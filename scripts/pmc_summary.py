@@ -8,7 +8,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"]
-        if "stream_kernel" not in name and "tile_kernel" not in name and "finalize" not in name and "rgb_pass" not in name and "metering" not in name:
+        if "frame_kernel" not in name and "stream_kernel" not in name and "tile_kernel" not in name and "finalize" not in name and "rgb_pass" not in name and "metering" not in name:
             continue
         short = name[:75]
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -58,6 +58,11 @@ SIGNATURES = {
                                                  _P, POINTER(_P), c_int]),
     "mi_isp_pipeline12_pass": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_float,
                                        c_float, c_float, c_int, _P, _P]),
+    "mi_isp_pipeline12_graph_create": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, c_int,
+                                               POINTER(c_float), c_int, c_int, c_float, c_float, c_float, c_float, _P,
+                                               c_int, c_int, POINTER(_P)]),
+    "mi_isp_pipeline12_graph_launch": (c_int, [_P, _P]),
+    "mi_isp_pipeline12_graph_destroy": (c_int, [_P]),
     "mi_isp_pipeline12_reinhard_whole_frame": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_float, c_float,
                                                c_float, c_float, _P, _P]),
     "mi_isp_pipeline12_whole_frame_fits": (c_int, [c_int, c_int, c_int]),

@@ -141,6 +141,7 @@ extern "C" int mi_isp_load_packed_scale_supported(float scale) { return rtile::s
 // ---- measurement aid: HIP events around each data pass, on the stream it runs on ---------------------
 #include <vector>
 static struct {
+  std::mutex mu;                  // the ABI is callable from several threads (one per stream)
   bool on = false;
   std::vector<hipEvent_t> ev;     // 8 per sampled frame: (start, stop) x 4 passes
   size_t used = 0;
@@ -149,6 +150,7 @@ static struct {
 } g_prof;
 
 extern "C" int mi_isp_profile_enable(int max_frames, int every) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.clear();
   g_prof.used = 0;
@@ -165,6 +167,7 @@ extern "C" int mi_isp_profile_enable(int max_frames, int every) {
 
 extern "C" int mi_isp_profile_collect(float avg_us[4], int* count) {
   MI_REQUIRE(avg_us && count, "profile_collect: null pointer");
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   double sum[4] = {0, 0, 0, 0};
   int n = 0;
   for (size_t f = 0; f + 8 <= g_prof.used; f += 8, ++n) {
@@ -188,6 +191,10 @@ struct PassTimer {
   int end(int k) const { if (on) MI_HIP(hipEventRecord(g_prof.ev[base + 2 * k + 1], s)); return 0; }
 };
 static PassTimer pass_timer(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (g_prof.on) (void)hipStreamIsCapturing(s, &cap);
+  if (cap != hipStreamCaptureStatusNone) return PassTimer{0, false, s};   // events inside a graph cannot be timed
   const bool sampled = g_prof.on && (g_prof.frames_seen++ % g_prof.every) == 0;
   PassTimer t = {g_prof.used, sampled && g_prof.used + 8 <= g_prof.ev.size(), s};
   if (t.on) g_prof.used += 8;
@@ -453,6 +460,97 @@ extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, vo
                                   (hipStream_t)streams[i % n_streams], "pipeline12_reinhard_batch"))
       return rc;
   }
+  return 0;
+}
+
+// ---- a batch as a HIP graph: capture once, replay per step ---------------------------------------------------------
+// What BatchPipeline(use_graph=True) has, for C callers: the step - fork to `n_streams` internal streams, the launches of
+// every frame (frame i on stream i % n_streams), join - is captured into a graph bound to the given buffers; a replay
+// has no launch gaps between the dependent kernels of a stream.  whole_frame: every frame through the single-launch
+// kernel, one after the other on one stream (two of them must not overlap).
+struct BatchGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> events;
+};
+
+static void batch_graph_free(BatchGraph* b) {
+  if (!b) return;
+  if (b->exec) (void)hipGraphExecDestroy(b->exec);
+  if (b->graph) (void)hipGraphDestroy(b->graph);
+  for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
+  for (hipStream_t s : b->streams) (void)hipStreamDestroy(s);
+  delete b;
+}
+
+extern "C" int mi_isp_pipeline12_whole_frame_fits(int H, int W, int out_dtype);
+extern "C" int mi_isp_pipeline12_graph_create(const uint8_t* const* packed, void* const* out, void* const* work_images,
+                                              int n_frames, int H, int W, int ids_format, int pattern,
+                                              const float* ccm9, int work_dtype, int out_dtype, float gamma,
+                                              float intensity, float light_adapt, float color_adapt, void* ws,
+                                              int n_streams, int whole_frame, void** handle) {
+  MI_REQUIRE(packed && out && ws && handle, "pipeline12_graph_create: null pointer");
+  MI_REQUIRE(n_frames > 0 && n_streams >= 1, "pipeline12_graph_create: need at least one frame and one stream");
+  if (whole_frame) {
+    n_streams = 1;
+    (void)mi_isp_pipeline12_whole_frame_fits(H, W, out_dtype);   // device queries happen outside the capture
+  }
+  BatchGraph* b = new BatchGraph();
+  auto fail = [&](int rc) { batch_graph_free(b); return rc; };
+#define MI_HIP_G(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      mi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
+      return fail(2);                                                                               \
+    }                                                                                               \
+  } while (0)
+  for (int i = 0; i < n_streams; ++i) {
+    hipStream_t s;
+    MI_HIP_G(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    b->streams.push_back(s);
+  }
+  for (int i = 0; i < n_streams; ++i) {
+    hipEvent_t e;
+    MI_HIP_G(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    b->events.push_back(e);
+  }
+  hipStream_t s0 = b->streams[0];
+  MI_HIP_G(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
+  MI_HIP_G(hipEventRecord(b->events[0], s0));                                   // fork
+  for (int i = 1; i < n_streams; ++i) MI_HIP_G(hipStreamWaitEvent(b->streams[i], b->events[0], 0));
+  const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
+  int rc = 0;
+  for (int i = 0; i < n_frames && rc == 0; ++i) {
+    float* wsi = static_cast<float*>(ws) + (size_t)i * ws_floats;
+    rc = pipeline12_frame(packed[i], out[i], work_images ? work_images[i] : nullptr, H, W, ids_format, pattern, ccm9,
+                          work_dtype, out_dtype, gamma, intensity, light_adapt, color_adapt, wsi,
+                          b->streams[i % n_streams], "pipeline12_graph_create", whole_frame);
+  }
+  for (int i = 1; i < n_streams; ++i) {                                          // join
+    (void)hipEventRecord(b->events[i], b->streams[i]);
+    (void)hipStreamWaitEvent(s0, b->events[i], 0);
+  }
+  hipGraph_t g = nullptr;
+  const hipError_t ec = hipStreamEndCapture(s0, &g);
+  b->graph = g;
+  if (rc != 0) return fail(rc);
+  if (ec != hipSuccess) { mi_set_error("pipeline12_graph_create: capture failed: %s", hipGetErrorString(ec)); return fail(2); }
+  MI_HIP_G(hipGraphInstantiate(&b->exec, b->graph, nullptr, nullptr, 0));
+#undef MI_HIP_G
+  *handle = b;
+  return 0;
+}
+
+extern "C" int mi_isp_pipeline12_graph_launch(void* handle, void* stream) {
+  MI_REQUIRE(handle, "pipeline12_graph_launch: null handle");
+  MI_HIP(hipGraphLaunch(static_cast<BatchGraph*>(handle)->exec, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int mi_isp_pipeline12_graph_destroy(void* handle) {
+  batch_graph_free(static_cast<BatchGraph*>(handle));
   return 0;
 }
 

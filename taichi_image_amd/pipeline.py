@@ -67,8 +67,11 @@ class BatchPipeline:
 
     def __init__(self, n_frames, H, W, device, n_streams=2, pattern=BayerPattern.RGGB, ids_format=False,
                  correct_colors=None, work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0,
-                 light_adapt=1.0, color_adapt=0.0, use_graph=False):
+                 light_adapt=1.0, color_adapt=0.0, use_graph=False, whole_frame=False):
         self.n_frames, self.H, self.W, self.device = n_frames, H, W, device
+        self.whole_frame = bool(whole_frame)          # every frame through the single-launch kernel (csrc/isp_mega.h)
+        if self.whole_frame:
+            n_streams = 1                             # two whole-frame grids must never share the chip
         self.work, self.odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
         self.pattern, self.ids = pattern, int(bool(ids_format))
         self.ccm = _native.ccm_arg(correct_colors)
@@ -83,11 +86,20 @@ class BatchPipeline:
         self.work_images = None if self.odt.code == self.work.code else [
             torch.empty((H, W, 3), dtype=self.work.torch, device=device) for _ in range(n_frames)]
         self.work_ptrs = None if self.work_images is None else _native.ptr_array(self.work_images)
-        # use_graph: the step (fork to the worker streams, 4 launches per frame, join) is captured once
-        # into a HIP graph and replayed while the input tensors keep their addresses (a ring of
-        # upload buffers does); replay removes the launch gaps between the dependent kernels
+        # use_graph: the step (fork to the worker streams, the launches of every frame, join) is captured once
+        # into a HIP graph inside the library (mi_isp_pipeline12_graph_create) and replayed while the input
+        # tensors keep their addresses (a ring of upload buffers does); replay removes the launch gaps between
+        # the dependent kernels
         self.use_graph = bool(use_graph)
         self._graph, self._graph_key = None, None
+
+    def __del__(self):
+        g = getattr(self, "_graph", None)
+        if g is not None:
+            try:
+                _native.lib().mi_isp_pipeline12_graph_destroy(g)
+            except Exception:
+                pass
 
     def __call__(self, frames, eager=False):
         assert len(frames) == self.n_frames
@@ -98,14 +110,17 @@ class BatchPipeline:
             if self._graph is None or key != self._graph_key:
                 self._issue(frames)                          # warm (lazy initialisation stays out of the capture)
                 torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                cap = torch.cuda.Stream(device=self.device)
-                with torch.cuda.stream(cap):
-                    with torch.cuda.graph(g, stream=cap):
-                        self._issue(frames)
-                torch.cuda.synchronize(self.device)
-                self._graph, self._graph_key, self._graph_inputs = g, key, list(frames)   # keep the inputs alive
-            self._graph.replay()
+                if self._graph is not None:
+                    _native.check(_native.lib().mi_isp_pipeline12_graph_destroy(self._graph))
+                    self._graph = None
+                handle = _native.c_void_p()
+                g_, i_, la_, ca_ = self.params
+                _native.check(_native.lib().mi_isp_pipeline12_graph_create(
+                    _native.ptr_array(frames), self.out_ptrs, self.work_ptrs, self.n_frames, self.H, self.W, self.ids,
+                    self.pattern.value, self.ccm, self.work.code, self.odt.code, g_, i_, la_, ca_, self.ws.data_ptr(),
+                    len(self.streams), int(self.whole_frame), _native.ctypes.byref(handle)))
+                self._graph, self._graph_key, self._graph_inputs = handle, key, list(frames)   # keep the inputs alive
+            _native.check(_native.lib().mi_isp_pipeline12_graph_launch(self._graph, _native.stream_ptr(self.device)))
             return self.outputs
         return self._issue(frames)
 
@@ -124,6 +139,15 @@ class BatchPipeline:
             s.wait_stream(cur)
         in_ptrs = _native.ptr_array(frames)
         g, i, la, ca = self.params
+        if self.whole_frame:
+            ws_bytes = int(_native.lib().mi_isp_workspace_bytes(self.H, self.W))
+            with torch.cuda.stream(self.streams[0]):
+                for k, f in enumerate(frames):
+                    _native.check(_native.lib().mi_isp_pipeline12_reinhard_whole_frame(
+                        f.data_ptr(), self.outputs[k].data_ptr(), self.H, self.W, self.ids, self.pattern.value, self.ccm,
+                        self.odt.code, g, i, la, ca, self.ws.data_ptr() + k * ws_bytes, self.streams[0].cuda_stream))
+            cur.wait_stream(self.streams[0])
+            return self.outputs
         _native.check(_native.lib().mi_isp_pipeline12_reinhard_batch(
             in_ptrs, self.out_ptrs, self.work_ptrs, self.n_frames, self.H, self.W, self.ids, self.pattern.value, self.ccm,
             self.work.code, self.odt.code, g, i, la, ca, self.ws.data_ptr(), self.stream_ptrs, len(self.streams)))
