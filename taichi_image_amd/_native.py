@@ -90,10 +90,12 @@ def lib() -> ctypes.CDLL:
                         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(or `make -C taichi_image_amd/csrc`).  There is no CPU fallback.")
                 L = ctypes.CDLL(LIB_PATH)
+                guarded = _GuardedLibrary()
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)   # AttributeError if the library lacks a declared symbol
                     fn.restype, fn.argtypes = res, args
-                _lib = L
+                    setattr(guarded, name, _Guarded(fn))
+                _lib = guarded
     return _lib
 
 
@@ -107,8 +109,38 @@ def require_gpu() -> None:
         raise RuntimeError("taichi_image_amd needs an MI355X (HIP) device; there is no CPU fallback")
 
 
+class _StreamArg(int):
+    """A hipStream_t value that remembers which device it belongs to (see _Guarded)."""
+    device = None
+
+
 def stream_ptr(device: torch.device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    s = _StreamArg(torch.cuda.current_stream(device).cuda_stream)
+    s.device = device
+    return s
+
+
+class _Guarded:
+    """A library entry point that launches on the device its stream argument belongs to.
+
+    The C ABI launches on the CURRENT device (a null stream is every device's default stream), while the call surface
+    takes `device=` arguments and tensors of any GPU (camera_isp.py:239-251 of the reference does too).  Every wrapper
+    passes its stream through stream_ptr(device); when that device is not the current one the call runs under
+    torch.cuda.device(device), so pointers, workspace and launch agree."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        dev = next((a.device for a in args if isinstance(a, _StreamArg)), None)
+        if dev is None or dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return self.fn(*args)
+        with torch.cuda.device(dev):
+            return self.fn(*args)
+
+
+class _GuardedLibrary:
+    pass
 
 
 def ccm_arg(correct_colors):

@@ -337,8 +337,9 @@ __constant__ const tile::BorderTable BORDER_TC = tile::make_border_table();
 // make the wave drain its prefetched rows (s_waitcnt vmcnt(0)) - measured 3x on the edge bands of every frame.
 
 // x * 16 / T for a compile-time weight sum T: q = a * RN(1/T) with one exact residual step (a = 16 x).  Equal to the
-// IEEE quotient a / T for EVERY finite float a and every T that occurs (exhaustive check over all 2^32 bit patterns:
-// tests/test_oracle.py::test_border_division_by_reciprocal runs oracle/check_recip_div.c).
+// IEEE quotient a / T for every finite float a with a normal quotient (|a| >= 2^-120) or a == +0 and every T that occurs
+// (exhaustive check over all 2^32 bit patterns: tests/test_oracle.py::test_border_division_by_reciprocal runs
+// oracle/check_recip_div.c; a pixel accumulator is zero or at least 2^-29 in magnitude).
 template <int T> MI_DEV float div16_by(float x) {
   if constexpr (T == 16) {
     return x;

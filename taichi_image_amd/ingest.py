@@ -95,9 +95,13 @@ def load_raw_bytes(filepath, device: torch.device = torch.device("cuda")) -> tor
         got = f.readinto(pinned.numpy())
     assert got == size, f"short read on {filepath}"
     dev = device if device.index is not None else torch.device(device.type, torch.cuda.current_device())
+    # the destination is allocated on the caller-side (default) stream's pool, NOT on the copy stream's: the consumer
+    # frees it in stream order with its own kernels, and a block owned by a pooled side stream could be handed to a
+    # later upload while those kernels still read it
+    out = torch.empty(size, dtype=torch.uint8, device=dev)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        out = pinned.to(dev, non_blocking=True)
+        out.copy_(pinned, non_blocking=True)
     stream.synchronize()                                # the worker thread waits, not the caller of the iterator
     return out
 

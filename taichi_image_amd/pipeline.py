@@ -115,10 +115,11 @@ class BatchPipeline:
                     self._graph = None
                 handle = _native.c_void_p()
                 g_, i_, la_, ca_ = self.params
-                _native.check(_native.lib().mi_isp_pipeline12_graph_create(
-                    _native.ptr_array(frames), self.out_ptrs, self.work_ptrs, self.n_frames, self.H, self.W, self.ids,
-                    self.pattern.value, self.ccm, self.work.code, self.odt.code, g_, i_, la_, ca_, self.ws.data_ptr(),
-                    len(self.streams), int(self.whole_frame), _native.ctypes.byref(handle)))
+                with torch.cuda.device(self.device):
+                    _native.check(_native.lib().mi_isp_pipeline12_graph_create(
+                        _native.ptr_array(frames), self.out_ptrs, self.work_ptrs, self.n_frames, self.H, self.W,
+                        self.ids, self.pattern.value, self.ccm, self.work.code, self.odt.code, g_, i_, la_, ca_,
+                        self.ws.data_ptr(), len(self.streams), int(self.whole_frame), _native.ctypes.byref(handle)))
                 self._graph, self._graph_key, self._graph_inputs = handle, key, list(frames)   # keep the inputs alive
             _native.check(_native.lib().mi_isp_pipeline12_graph_launch(self._graph, _native.stream_ptr(self.device)))
             return self.outputs
@@ -133,6 +134,10 @@ class BatchPipeline:
             torch.cuda.synchronize(self.device)
 
     def _issue(self, frames):
+        with torch.cuda.device(self.device):          # the batch entry points take raw stream arrays: guard here
+            return self._issue_on_device(frames)
+
+    def _issue_on_device(self, frames):
         # the frames were produced on the current stream: make the worker streams wait for it
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:

@@ -90,3 +90,27 @@ def test_dtype_tokens():
     with pytest.raises(ValueError):
         types.ti_type([1, 2, 3])
     assert types.scale_factor[types.u16] == 65535
+
+
+def test_native_calls_run_on_the_device_of_their_stream(monkeypatch):
+    """a call whose stream belongs to a GPU other than the current one must run under that device
+    (pointers, workspace and launch then agree); unit test of the guard with a fake entry point."""
+    import torch
+    from taichi_image_amd import _native
+    entered = []
+
+    class FakeGuard:
+        def __init__(self, dev): self.dev = dev
+        def __enter__(self): entered.append(self.dev)
+        def __exit__(self, *a): entered.append("exit")
+
+    monkeypatch.setattr(torch.cuda, "device", FakeGuard)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    calls = []
+    fn = _native._Guarded(lambda *a: calls.append(a) or 0)
+    s1 = _native._StreamArg(0); s1.device = torch.device("cuda", 1)
+    s0 = _native._StreamArg(0); s0.device = torch.device("cuda", 0)
+    assert fn(1, 2, s1) == 0 and entered == [torch.device("cuda", 1), "exit"]
+    entered.clear()
+    assert fn(1, 2, s0) == 0 and fn(3) == 0 and entered == []          # current device / no stream: no switch
+    assert len(calls) == 3 and int(calls[0][2]) == 0

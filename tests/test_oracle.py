@@ -234,3 +234,122 @@ def test_demosaic_equals_published_malvar_he_cutler(rng):
         want = np.clip(np.stack([R, G, B], -1), 0, 1)
         got = O.bayer_to_rgb(cfa.astype(np.float32), pattern).astype(np.float64)
         assert np.abs(got[2:-2, 2:-2] - want[2:-2, 2:-2]).max() < 2e-6, f"pattern {pattern}"
+
+
+# ---------------------------------------------------------------------------------------------
+# Independent pins of the stages that otherwise rest on the restatement alone (round-2 verdict, item 8)
+# ---------------------------------------------------------------------------------------------
+def _published_filters():
+    """The four 5x5 Malvar-He-Cutler filters (coefficients in eighths) per output colour and site kind."""
+    g_at_rb = np.array([[0, 0, -1, 0, 0], [0, 0, 2, 0, 0], [-1, 2, 4, 2, -1], [0, 0, 2, 0, 0], [0, 0, -1, 0, 0]], float)
+    row = np.array([[0, 0, 0.5, 0, 0], [0, -1, 0, -1, 0], [-1, 4, 5, 4, -1], [0, -1, 0, -1, 0], [0, 0, 0.5, 0, 0]], float)
+    diag = np.array([[0, 0, -1.5, 0, 0], [0, 2, 0, 2, 0], [-1.5, 0, 6, 0, -1.5], [0, 2, 0, 2, 0], [0, 0, -1.5, 0, 0]], float)
+    ident = np.zeros((5, 5)); ident[2, 2] = 8.0
+    return g_at_rb, row, row.T.copy(), diag, ident
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (6, 8), (2, 6)])
+def test_border_renormalisation_from_the_published_filters(rng, shape):
+    """bayer.py:138-155 at the image frame: only in-bounds taps contribute and the sum is divided by the in-bounds
+    weight sum.  Expected values are built here, pixel by pixel with plain loops, from the published 5x5 filters -
+    not from the oracle's tap tables - for images in which EVERY pixel is a border pixel, all four patterns."""
+    g_at_rb, row, col, diag, ident = _published_filters()
+    H, W = shape
+    cfa = rng.random((H, W)).astype(np.float32)
+    red_site = {O.RGGB: (0, 0), O.GRBG: (0, 1), O.GBRG: (1, 0), O.BGGR: (1, 1)}
+    for pattern, (pr, pc) in red_site.items():
+        want = np.zeros((H, W, 3))
+        for r in range(H):
+            for c in range(W):
+                is_r = (r % 2 == pr) and (c % 2 == pc)
+                is_b = (r % 2 != pr) and (c % 2 != pc)
+                g_r_row = (r % 2 == pr) and (c % 2 != pc)
+                if is_r: fs = (ident, g_at_rb, diag)
+                elif is_b: fs = (diag, g_at_rb, ident)
+                elif g_r_row: fs = (row, ident, col)         # green with red left / right
+                else: fs = (col, ident, row)                 # green with red above / below
+                for ch, f in enumerate(fs):
+                    num = den = 0.0
+                    for dr in range(-2, 3):
+                        for dc in range(-2, 3):
+                            if 0 <= r + dr < H and 0 <= c + dc < W and f[dr + 2, dc + 2] != 0:
+                                num += float(cfa[r + dr, c + dc]) * f[dr + 2, dc + 2]
+                                den += f[dr + 2, dc + 2]
+                    want[r, c, ch] = min(max(num / den, 0.0), 1.0)
+        got = O.bayer_to_rgb(cfa, pattern).astype(np.float64)
+        assert np.abs(got - want).max() < 3e-6, f"pattern {pattern} shape {shape}"
+
+
+def test_bilinear_hand_computed_3x3_to_2x2():
+    """interpolate.py:24-34,59-66 by hand: dst (r, c) samples p = (r / s, c / s) with s = 2/3 (no half-pixel offset),
+    taps at trunc(p) and trunc(p) + 1 clamped to the edge, mix(x, y, a) = x (1 - a) + y a on rows, then columns."""
+    src = np.array([[[0.0, 10.0, 100.0], [1.0, 11.0, 101.0], [2.0, 12.0, 102.0]],
+                    [[3.0, 13.0, 103.0], [4.0, 14.0, 104.0], [5.0, 15.0, 105.0]],
+                    [[6.0, 16.0, 106.0], [7.0, 17.0, 107.0], [8.0, 18.0, 108.0]]], np.float32)
+    got = O.resize_bilinear(src, (2, 2), 2.0 / 3.0)
+    # destination (0,0): p = (0, 0) -> src[0,0].  (0,1): p = (0, 1.5): halfway between columns 1 and 2 of row 0.
+    # (1,0): p = (1.5, 0): halfway between rows 1 and 2 of column 0.  (1,1): the mean of the four lower-right pixels.
+    want = np.array([[src[0, 0], (src[0, 1] + src[0, 2]) / 2],
+                     [(src[1, 0] + src[2, 0]) / 2, (src[1, 1] + src[1, 2] + src[2, 1] + src[2, 2]) / 4]], np.float32)
+    assert np.allclose(got, want, rtol=0, atol=1e-5), (got, want)
+    # clamp-to-edge: upscaling 2x reads index 1 + 1 = 2 -> clamped to 1 at the last destination column
+    up = O.resize_bilinear(src[:2, :2], (4, 4), 2.0)
+    assert np.allclose(up[0, 3], (src[0, 1] + src[0, 1]) / 2) and np.allclose(up[0, 1], (src[0, 0] + src[0, 1]) / 2)
+
+
+def _reinhard_devlin(rgb, key_bounds, log_mean, chan_mean, lum_mean, f_prime, a, c):
+    """Reinhard & Devlin, "Dynamic range reduction inspired by photoreceptor physiology" (IEEE TVCG 2005), eqs. 1-7 in
+    float64: V = I / (I + (f Ia)^m), Ia = a Il + (1 - a) Ig, Il = c Ic + (1 - c) L, Ig = c Cav + (1 - c) Lav,
+    f = exp(-f'), m = 0.3 + 0.7 k^1.4, k = (Lmax - Lav) / (Lmax - Lmin) on log luminances."""
+    lmin, lmax = key_bounds
+    k = (lmax - log_mean) / (lmax - lmin)
+    m = 0.3 + 0.7 * k ** 1.4
+    f = np.exp(-f_prime)
+    L = rgb @ np.array([0.299, 0.587, 0.114])
+    Il = c * rgb + (1 - c) * L[..., None]
+    Ig = c * np.asarray(chan_mean) + (1 - c) * lum_mean
+    Ia = a * Il + (1 - a) * Ig
+    return rgb / (rgb + (f * Ia) ** m)
+
+
+@pytest.mark.parametrize("a,c,fp", [(1.0, 0.0, 1.0), (0.6, 0.3, 0.5), (0.0, 1.0, 2.0)])
+def test_reinhard_matches_the_published_photoreceptor_model(a, c, fp):
+    """camera_isp.py:186-218 and tonemap.py:108-131 against the published formula on a 2x2 image with hand-set
+    statistics.  light_adapt = a, color_adapt = c, intensity = f'.  The stateless path keeps the reference's sign
+    quirk (tonemap.py:102 stores -log_max): the published model with Lmax := -log_max, Lmin := log_min."""
+    img = np.array([[[0.9, 0.5, 0.2], [0.05, 0.10, 0.02]], [[0.30, 0.30, 0.30], [0.6, 0.1, 0.7]]], np.float64)
+    # ISP path: metering 9-vector = bounds (0, 1), log bounds, log mean, mean, rgb mean - set by hand
+    m9 = np.array([0.0, 1.0, -4.0, -0.1, -1.5, 0.35, 0.4, 0.3, 0.25], np.float32)
+    want = _reinhard_devlin(img, (m9[2], m9[3]), m9[4], m9[6:9], m9[5], fp, a, c)
+    _, after = O.reinhard_isp(img.astype(np.float32), m9, gamma=1.0, intensity=fp, light_adapt=a, color_adapt=c)
+    assert np.abs(after.astype(np.float64) - want).max() < 2e-6 * 4
+    # and the u8 output of the second pass: 255 (p / max p)^(1 / gamma), truncated
+    u8, _ = O.reinhard_isp(img.astype(np.float32), m9, gamma=0.6, intensity=fp, light_adapt=a, color_adapt=c)
+    want8 = np.floor(255.0 * (want / max(1e-6, want.max())) ** (1 / 0.6))
+    assert np.abs(u8.astype(np.float64) - want8).max() <= 1
+    # stateless path: statistics computed by the oracle itself from the normalised image; rebuild the expectation
+    # from those statistics with the published formula and the sign quirk
+    out, st = O.tonemap_reinhard(img.astype(np.float32), 1.0, fp, a, c, "f32", return_intermediates=True)
+    t = np.clip((img - float(st["lo"])) / (float(st["hi"]) - float(st["lo"])), 0, 1)
+    g = t @ np.array([0.299, 0.587, 0.114])
+    lg = np.log(np.maximum(g, 1e-4))
+    assert abs(float(st["Bmin"]) - lg.min()) < 1e-6 and abs(float(st["Bmax"]) + lg.max()) < 1e-6   # (log_min, -log_max)
+    v = _reinhard_devlin(t, (float(st["Bmin"]), float(st["Bmax"])), lg.mean(), t.reshape(-1, 3).mean(0), g.mean(), fp, a, c)
+    want_out = (v - v.min()) / (v.max() - v.min())
+    assert np.abs(out.astype(np.float64) - want_out).max() < 1e-5
+
+
+def test_border_division_by_reciprocal():
+    """csrc/isp_stream.h div16_by<T>: q = a RN(1/T), e = fma(-q, T, a), q' = fma(e, RN(1/T), q) equals the IEEE
+    quotient a / T for the weight sums T that occur at the left / right image edge (11, 14, 15, 18, 19).
+    oracle/check_recip_div.c checks EVERY finite float (2^32 patterns; MI_ISP_EXHAUSTIVE=1, ~2 min); the default run
+    takes every 97th bit pattern.  The only exceptions are numerators whose quotient is subnormal (|a| < 2^-120) and -0,
+    which an accumulated pixel value cannot be (zero or at least 2^-29 in magnitude; at least one positive weight)."""
+    import subprocess, tempfile
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "check_recip_div.c")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "check")
+        subprocess.run(["gcc", "-O2", "-march=x86-64-v3", "-fopenmp", "-ffp-contract=off", src, "-o", exe, "-lm"], check=True)
+        stride = "1" if os.environ.get("MI_ISP_EXHAUSTIVE") else "97"
+        out = subprocess.run([exe, stride], check=True, capture_output=True, text=True).stdout
+    assert "FAIL" not in out and out.count("ok") == 5, out

@@ -34,14 +34,18 @@ def test_natural_sort_and_discovery(tmp_path):
         (tmp_path / cam).mkdir()
         for n in names:
             (tmp_path / cam / n).write_bytes(b"\0\0")
-    folders, names = ts.find_scan_folders(tmp_path)
-    assert [f.name for f in folders] == ["cam2", "cam10"] and names == ["f1.raw", "f10.raw"]
-    assert ts.find_folder_images(tmp_path / "cam2") == ([tmp_path / "cam2"], ["f1.raw", "f2.raw", "f10.raw"])
+    index = ts.ScanIndex.of_scan(tmp_path)
+    assert [f.name for f in index.cameras] == ["cam2", "cam10"] and index.frames == ["f1.raw", "f10.raw"]
+    single = ts.ScanIndex.of_directory(tmp_path / "cam2")
+    assert single.cameras == [tmp_path / "cam2"] and single.frames == ["f1.raw", "f2.raw", "f10.raw"]
     with pytest.raises(FileNotFoundError):
-        ts.find_scan_folders(tmp_path / "missing")
+        ts.ScanIndex.of_scan(tmp_path / "missing")
     (tmp_path / "cam3").mkdir(); (tmp_path / "cam3" / "other.raw").write_bytes(b"\0\0")
     with pytest.raises(ValueError):
-        ts.find_scan_folders(tmp_path)
+        ts.ScanIndex.of_scan(tmp_path)
+    (tmp_path / "void").mkdir()
+    with pytest.raises(ValueError):
+        ts.ScanIndex.of_scan(tmp_path / "void")
 
 
 def test_png_writer_round_trip(tmp_path):
@@ -53,7 +57,7 @@ def test_png_writer_round_trip(tmp_path):
 def test_grid_and_parser():
     import torch
     ims = [torch.full((2, 3, 3), i, dtype=torch.uint8) for i in range(5)]
-    g = ts.concat_image_grid(ims[:4], rows=2)
+    g = ts.tile_grid(ims[:4], rows=2)
     assert g.shape == (4, 6, 3) and int(g[0, 3, 0]) == 1 and int(g[2, 0, 0]) == 2
     a = ts.build_parser().parse_args(["--images", "x", "--transform", "none", "--rows", "1"])
     assert a.transform.value == "none" and a.gamma == 0.9 and a.intensity == 3.0 and a.moving_alpha == 0.02
