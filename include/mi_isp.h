@@ -118,6 +118,14 @@ int mi_isp_metering_bounds(const void* const* images_host, int n_images, int H, 
 int mi_isp_metering_sums(const void* const* images_host, int n_images, int H, int W, int stride,
                          int dtype, const float* bounds2_dev, float* out8_dev, void* ws_dev,
                          void* stream);
+/* The sharded batch after an all-gather of the ranks' partials (one all-gather per round, then one of these):
+ *  combine_bounds: gathered_dev = n_ranks x [min, max] -> bounds2_out_dev = the blended bounds of camera_isp.py:156-157
+ *  combine_sums  : gathered_dev = n_ranks x the 8 floats of mi_isp_metering_sums -> state9_dev updated in place
+ *                  (camera_isp.py:131-134,164-166), equal to what mi_isp_metering computes over all ranks' images. */
+int mi_isp_metering_combine_bounds(const float* gathered_dev, int n_ranks, const float* state9_dev, float alpha,
+                                   float* bounds2_out_dev, void* stream);
+int mi_isp_metering_combine_sums(const float* gathered_dev, int n_ranks, const float* bounds2_dev, float* state9_dev,
+                                 float alpha, void* stream);
 /* reinhard_kernel (camera_isp.py:177-218): pass 1 writes p back into image_dev IN PLACE (as the
  * reference does) and reduces max(p); pass 2 writes u8.  transform != NONE applies
  * interpolate.transform (camera_isp.py:403) while storing; out_dev is then the transformed shape. */
@@ -179,6 +187,22 @@ int mi_isp_pipeline12_reinhard(const uint8_t* packed_dev, void* out_dev, void* w
                                int ids_format, int pattern, const float* ccm9_host,
                                int work_dtype, int out_dtype, float gamma, float intensity,
                                float light_adapt, float color_adapt, void* ws_dev, void* stream);
+/* One camera group from packed bytes to u8 outputs in one call on the caller's stream (ISP.load_packed12/16 per
+ * camera, camera_isp.py:333-347; the rolling metering over the group, :376-385 -> :142-175; ISP.tonemap_reinhard or
+ * tonemap_linear, :394-413, with the orientation transform folded into the store).
+ *   packed_host / images_host / outs_host: host arrays of n device pointers; images are (Hd, Wd, 3) work-dtype buffers
+ *   owned by the caller - after the call they hold what the reference leaves in them (the loaded image for the linear
+ *   map, the Reinhard-mapped p for Reinhard, camera_isp.py:211); outs are u8 (Hd, Wd, 3), or the transformed shape.
+ *   bits 12 / 16; scale > 0: demosaic + bilinear resize fused (Hd, Wd = ISP.resize_image's size; the scale must
+ *   satisfy mi_isp_load_packed_scale_supported), scale <= 0: Hd == H, Wd == W.
+ *   state9_dev: the ISP's metering 9-vector (in/out); alpha: 0 for the first group, 1 - moving_alpha afterwards
+ *   (camera_isp.py:376-385).  tonemap: 0 = Reinhard (gamma, intensity, light_adapt, color_adapt), 1 = linear (gamma). */
+int mi_isp_camera_frame_batch(const uint8_t* const* packed_host, void* const* images_host, uint8_t* const* outs_host,
+                              int n, int H, int W, int bits, int ids_format, int pattern, const float* ccm9_host,
+                              int work_dtype, int Hd, int Wd, float scale, int metering_stride, float* state9_dev,
+                              float alpha, int tonemap, float gamma, float intensity, float light_adapt,
+                              float color_adapt, int transform, void* ws_dev, void* stream);
+
 /* The same chain (test/pipeline.py:26-32) as ONE persistent launch (csrc/isp_mega.h): the frame is demosaiced once,
  * the f16 RGB image stays in registers and LDS, the three global dependencies of tonemap.py:146-154 are grid
  * barriers inside the kernel; HBM sees the packed frame in and the output out.  f16 work dtype; out_dtype u8 / u16 /

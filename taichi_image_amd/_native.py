@@ -58,6 +58,11 @@ SIGNATURES = {
                                                  _P, POINTER(_P), c_int]),
     "mi_isp_pipeline12_pass": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_float,
                                        c_float, c_float, c_int, _P, _P]),
+    "mi_isp_metering_combine_bounds": (c_int, [_P, c_int, _P, c_float, _P, _P]),
+    "mi_isp_metering_combine_sums": (c_int, [_P, c_int, _P, _P, c_float, _P]),
+    "mi_isp_camera_frame_batch": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, c_int, c_int,
+                                          POINTER(c_float), c_int, c_int, c_int, c_float, c_int, _P, c_float, c_int, c_float,
+                                          c_float, c_float, c_float, c_int, _P, _P]),
     "mi_isp_pipeline12_graph_create": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, c_int,
                                                POINTER(c_float), c_int, c_int, c_float, c_float, c_float, c_float, _P,
                                                c_int, c_int, POINTER(_P)]),

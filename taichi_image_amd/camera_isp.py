@@ -251,17 +251,24 @@ def camera_isp(name: str, dtype=types.f32):
                 _native.check(L.mi_isp_metering(ptrs, len(images), H, W, self.metering_stride, dtype.code,
                                                 metering.data_ptr(), float(t), ws.data_ptr(), stream))
                 return metering
-            # sharded batch: same arithmetic with two tiny RCCL exchanges between the data passes
+            # sharded batch: the same two data passes, an all-gather after each (two collectives per call), the ranks'
+            # rows combined by one small kernel each on this stream (mi_isp_metering_combine_*)
+            world = _dist.world_size(self.process_group)
             raw = torch.empty(2, dtype=torch.float32, device=self.device)
             _native.check(L.mi_isp_metering_bounds(ptrs, len(images), H, W, self.metering_stride, dtype.code,
                                                    raw.data_ptr(), ws.data_ptr(), stream))
-            raw = _dist.allreduce_bounds(raw, self.process_group)
-            b = _dist.blend_bounds(raw, prev, t)
+            gathered = _dist.all_gather_rows(raw, self.process_group)
+            b = torch.empty(2, dtype=torch.float32, device=self.device)
+            _native.check(L.mi_isp_metering_combine_bounds(gathered.data_ptr(), world, prev.data_ptr(), float(t),
+                                                           b.data_ptr(), stream))
             part = torch.empty(8, dtype=torch.float32, device=self.device)
             _native.check(L.mi_isp_metering_sums(ptrs, len(images), H, W, self.metering_stride, dtype.code,
                                                  b.data_ptr(), part.data_ptr(), ws.data_ptr(), stream))
-            part = _dist.allreduce_sums(part, self.process_group)
-            return _dist.finish_metering(prev, b, part, t)
+            gathered8 = _dist.all_gather_rows(part, self.process_group)
+            metering = prev.clone()
+            _native.check(L.mi_isp_metering_combine_sums(gathered8.data_ptr(), world, b.data_ptr(), metering.data_ptr(),
+                                                         float(t), stream))
+            return metering
 
         def update_metering(self, images: List[torch.Tensor]):
             """camera_isp.py:376-385."""

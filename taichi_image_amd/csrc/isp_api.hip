@@ -365,9 +365,17 @@ static bool force_cached() {
 #endif
 }
 
+static bool no_cached_pipeline() {
+#ifdef MI_ISP_MEASURE
+  static const bool off = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;   // measurement aid: the recompute tile chain
+  return off;
+#else
+  return false;
+#endif
+}
+
 static bool use_cached(const tile::Params& p, int work_dtype, int out_dtype) {
-  static const bool off = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
-  return !off && work_dtype == out_dtype && p.vec_store;
+  return !no_cached_pipeline() && work_dtype == out_dtype && p.vec_store;
 }
 
 static int pipeline_params(tile::Params& p, int H, int W, int ids_format, int pattern, const float* ccm9,
@@ -407,9 +415,8 @@ static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, 
   }
   if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && !force_cached())
     return pipeline_frame_stream(p, pattern, work_dtype, intensity, ws, -1, s);
-  static const bool no_cached = getenv("MI_ISP_NO_CACHED_PIPELINE") != nullptr;
   void* image = work_dtype == out_dtype ? out : work_image;
-  if (!no_cached && image && vec_store_ok(image, W, work_dtype))
+  if (!no_cached_pipeline() && image && vec_store_ok(image, W, work_dtype))
     return pipeline_frame_cached(p, pattern, work_dtype, gamma, intensity, ws, -1, s, image, out, out_dtype);
   p.dst = out;
   p.vec_store = vec_store_ok(out, W, out_dtype);
@@ -461,6 +468,43 @@ extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, vo
       return rc;
   }
   return 0;
+}
+
+// ---- one camera group, packed bytes -> u8 outputs, in one call -----------------------------------------------------------
+// ISP.load_packed12 / load_packed16 per camera (camera_isp.py:333-347, resize fused when scale > 0), the rolling
+// metering over the group (:376-385, :142-175), then ISP.tonemap_reinhard or tonemap_linear (:394-413) with the
+// orientation transform folded into the u8 store: what a frame group costs a C caller is this one call on its stream.
+extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
+                               float alpha, void* ws, void* stream);
+extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
+                                     const float* state9, float gamma, float intensity, float light_adapt,
+                                     float color_adapt, int transform, void* ws, void* stream);
+extern "C" int mi_isp_linear_batch(const void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
+                                   const float* state9, float gamma, int transform, void* ws, void* stream);
+
+extern "C" int mi_isp_camera_frame_batch(const uint8_t* const* packed, void* const* images, uint8_t* const* outs, int n,
+                                         int H, int W, int bits, int ids_format, int pattern, const float* ccm9,
+                                         int work_dtype, int Hd, int Wd, float scale, int metering_stride,
+                                         float* state9, float alpha, int tonemap, float gamma, float intensity,
+                                         float light_adapt, float color_adapt, int transform, void* ws, void* stream) {
+  MI_REQUIRE(packed && images && outs && state9 && ws, "camera_frame_batch: null pointer");
+  MI_REQUIRE(n >= 1, "camera_frame_batch: need at least one camera");
+  MI_REQUIRE(tonemap == 0 || tonemap == 1, "camera_frame_batch: tonemap must be 0 (reinhard) or 1 (linear)");
+  MI_REQUIRE(metering_stride >= 1, "camera_frame_batch: bad metering stride");
+  for (int i = 0; i < n; ++i) {
+    MI_REQUIRE(packed[i] && images[i] && outs[i], "camera_frame_batch: camera %d has a null buffer", i);
+    if (int rc = mi_isp_load_packed(packed[i], images[i], H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd, scale,
+                                    stream))
+      return rc;
+  }
+  if (int rc = mi_isp_metering(const_cast<const void* const*>(images), n, Hd, Wd, metering_stride, work_dtype, state9,
+                               alpha, ws, stream))
+    return rc;
+  if (tonemap == 0)
+    return mi_isp_reinhard_batch(images, outs, n, Hd, Wd, work_dtype, state9, gamma, intensity, light_adapt, color_adapt,
+                                 transform, ws, stream);
+  return mi_isp_linear_batch(const_cast<const void* const*>(images), outs, n, Hd, Wd, work_dtype, state9, gamma, transform,
+                             ws, stream);
 }
 
 // ---- a batch as a HIP graph: capture once, replay per step ---------------------------------------------------------
@@ -558,7 +602,11 @@ extern "C" int mi_isp_pipeline12_pass(const uint8_t* packed, void* out, int H, i
                                       const float* ccm9, int work_dtype, int out_dtype, float gamma,
                                       float light_adapt, float color_adapt, int pass, void* ws, void* stream) {
   MI_REQUIRE(out && ws, "pipeline12_pass: null pointer");
-  const int debug_skip = pass >> 4;      // measurement aid (see tile::Params::debug_skip)
+#ifdef MI_ISP_MEASURE
+  const int debug_skip = pass >> 4;      // measurement aid (see tile::Params::debug_skip); MI_ISP_MEASURE builds only
+#else
+  const int debug_skip = 0;
+#endif
   pass &= 15;
   MI_REQUIRE(pass >= 0 && pass <= 3, "pipeline12_pass: pass must be 0..3");
   tile::Params p = {};

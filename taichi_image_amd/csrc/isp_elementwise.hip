@@ -1044,7 +1044,11 @@ static int pass_blocks(int64_t n_px, int cap, bool reduce_only = false) {
   int64_t groups = (n_px + 7) / 8;
   int64_t b = (groups + PASS_THREADS - 1) / PASS_THREADS;
   if (b < 1) b = 1;
+#ifdef MI_ISP_MEASURE
   static const int env_limit = getenv("MI_ISP_PASS_BLOCKS") ? atoi(getenv("MI_ISP_PASS_BLOCKS")) : 0;   // measurement aid
+#else
+  constexpr int env_limit = 0;
+#endif
   const int limit = env_limit > 0 ? env_limit : (reduce_only ? 256 : 512);
   if (b > limit) b = limit;
   if (b > PASS_MAX_BLOCKS) b = PASS_MAX_BLOCKS;
@@ -1111,7 +1115,11 @@ int tonemap_reinhard_tail(const void* src, void* dst, int H, int W, int in_dtype
   const int nb = pass_blocks(a.n_px, cap), nbr = pass_blocks(a.n_px, cap, true);
   // measurement aid: MI_ISP_PULL_DEBUG=0 runs single passes (which > 0) on the scalars a full run left
   // in FrameParams, without the pulled finalize
+#ifdef MI_ISP_MEASURE
   static const char* dbg = getenv("MI_ISP_PULL_DEBUG");
+#else
+  const char* dbg = nullptr;
+#endif
   const int no_pull = (dbg && which > 0 && dbg[0] == '0') ? -1 : 0;
   const int dbg_bits = (dbg && which > 0 && dbg[0] > '0') ? (dbg[0] - '0') << 8 : 0;
   if (which < 0 || which == 1) {                                                      // tonemap.py:147-149
@@ -1394,6 +1402,54 @@ extern "C" int mi_isp_metering_sums(const void* const* images, int n_images, int
   fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp; fa.out = out8;
   fa.n_px = (float)((int64_t)n_images * hs * wss);
   return finalize(FIN_ISP_SUMS, fa, s);
+}
+
+// ---- the sharded batch (one process per GPU): combine the ranks' partials after an all-gather ---------------------------
+// Round 1: every rank contributes its raw [min, max]; round 2: its [log_min, log_max, sum_log, sum_gray, sum_r, sum_g,
+// sum_b, n].  Each round is ONE all-gather plus one of these single-thread kernels on the compute stream; the arithmetic
+// is the single-GPU finalize's (FIN_ISP_BOUNDS / FIN_ISP_STATS), so a sharded batch ends with the state an unsharded one
+// would have (up to the summation order of the partial sums).
+namespace {
+__global__ void metering_combine_bounds_kernel(const float* __restrict__ gathered, int n_ranks, const float* state9, float alpha,
+                                               float* bounds2) {
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  for (int r = 0; r < n_ranks; ++r) { lo = fminf(lo, gathered[2 * r]); hi = fmaxf(hi, gathered[2 * r + 1]); }
+  bounds2[0] = lo + alpha * (state9[0] - lo);          // camera_isp.py:156-157
+  bounds2[1] = hi + alpha * (state9[1] - hi);
+}
+__global__ void metering_combine_sums_kernel(const float* __restrict__ gathered, int n_ranks, const float* bounds2, float* state9,
+                                             float alpha) {
+  float lmin = __builtin_inff(), lmax = -__builtin_inff();
+  double sum[5] = {0, 0, 0, 0, 0}, n = 0;
+  for (int r = 0; r < n_ranks; ++r) {
+    const float* g = gathered + 8 * r;
+    lmin = fminf(lmin, g[0]); lmax = fmaxf(lmax, g[1]);
+    for (int k = 0; k < 5; ++k) sum[k] += (double)g[2 + k];
+    n += (double)g[7];
+  }
+  const float nn = (float)n;                            // camera_isp.py:131-134,164-166
+  const float v[9] = {bounds2[0], bounds2[1], lmin, lmax, (float)sum[0] / nn, (float)sum[1] / nn,
+                      (float)sum[2] / nn, (float)sum[3] / nn, (float)sum[4] / nn};
+  for (int i = 0; i < 9; ++i) state9[i] = v[i] + alpha * (state9[i] - v[i]);
+}
+}  // namespace
+
+extern "C" int mi_isp_metering_combine_bounds(const float* gathered, int n_ranks, const float* state9, float alpha,
+                                              float* bounds2_out, void* stream) {
+  MI_REQUIRE(gathered && state9 && bounds2_out && n_ranks >= 1, "metering_combine_bounds: bad arguments");
+  hipLaunchKernelGGL(metering_combine_bounds_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gathered, n_ranks, state9, alpha,
+                     bounds2_out);
+  MI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mi_isp_metering_combine_sums(const float* gathered, int n_ranks, const float* bounds2, float* state9, float alpha,
+                                            void* stream) {
+  MI_REQUIRE(gathered && bounds2 && state9 && n_ranks >= 1, "metering_combine_sums: bad arguments");
+  hipLaunchKernelGGL(metering_combine_sums_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gathered, n_ranks, bounds2, state9,
+                     alpha);
+  MI_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype,

@@ -32,6 +32,14 @@
 
 namespace tile {
 
+// measurement aid: Params::debug_skip switches parts of the tile kernel off (scripts/ablate*.py); release builds
+// compile the tests away (make EXTRA=-DMI_ISP_MEASURE keeps them)
+#ifdef MI_ISP_MEASURE
+#define MI_DEBUG_SKIP(p) ((p).debug_skip)
+#else
+#define MI_DEBUG_SKIP(p) 0
+#endif
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int B, int E, class F> MI_DEV void static_for(F&& f) {
   if constexpr (B < E) {
@@ -530,7 +538,7 @@ MI_DEV void wave_store_row_f16_clamped(half_t* dst, int W, int row0, int c0, int
 }
 
 MI_DEV void store_row_dyn(const Params& p, int r, int c, const float (&v)[24], int npx) {
-  if (p.debug_skip & 32) {                      // measurement aid: no global stores
+  if (MI_DEBUG_SKIP(p) & 32) {                      // measurement aid: no global stores
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 24; ++i) s += v[i];
@@ -606,7 +614,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   MI_STAMP(0);
   if constexpr (HOT == 1) fill_packed_fast<E>(p, lds, r0 - 2, c0 - 8);
   else if constexpr (HOT >= 2) fill_cfa_fast<CfaT>(p, lds, r0 - 2, c0 - 8);
-  else if (!(p.debug_skip & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
+  else if (!(MI_DEBUG_SKIP(p) & 1)) fill_tile<E>(p, lds, r0 - 2, c0 - 8);
   MI_STAMP(1);
   __syncthreads();
   MI_STAMP(2);
@@ -614,7 +622,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   const int tx = threadIdx.x & (STRIPS_X - 1), ty = threadIdx.x / STRIPS_X;
   const int r = r0 + STRIP_H * ty, c = c0 + STRIP_W * tx;
   // H, W even -> both rows, pixel pairs in.  HOT: W % 8 == 0, so a strip is all in or all out
-  const bool active = r < p.H && c < p.W && (HOT != 0 || !(p.debug_skip & 2));
+  const bool active = r < p.H && c < p.W && (HOT != 0 || !(MI_DEBUG_SKIP(p) & 2));
   const int npx = HOT != 0 ? 8 : (active ? (p.W - c < 8 ? p.W - c : 8) : 0);
 
   // tonemap scalars (uniform loads); unused ones are dead code per EPI
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   if (active) load_window(lds, tx, ty, win);
   // a full tile with 1/2-byte outputs is stored wave-cooperatively through the (now free) tile buffer
   const bool coop_store = STORES && (STAGE_F32 || p.out_dtype != MI_F32) && r0 + TILE_H <= p.H && c0 + TILE_W <= p.W &&
-                          (HOT != 0 || (p.vec_store && !(p.debug_skip & 32)));
+                          (HOT != 0 || (p.vec_store && !(MI_DEBUG_SKIP(p) & 32)));
   if (STORES) __syncthreads();                          // every wave holds its window
   MI_STAMP(3);
   void* stage = lds + (threadIdx.x >> 6) * WAVE_STAGE_FLOATS;   // 3 KB (7 KB for 4-byte outputs) per wave
@@ -645,13 +653,13 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
     const bool fast = p.in_scale == 1.f && r >= 2 && r + 1 < p.H - 2 && c >= 2 && c + 7 < p.W - 2;
     // Wave-uniform predicates (scalar branches): the slow blocks below are real branches that
     // interior waves skip, not per-lane selects the compiler would flatten into the fast stream.
-    const bool wave_has_slow = __builtin_amdgcn_ballot_w64(!fast) != 0 && !(p.debug_skip & 16);
+    const bool wave_has_slow = __builtin_amdgcn_ballot_w64(!fast) != 0 && !(MI_DEBUG_SKIP(p) & 16);
     const bool wave_all_full = HOT != 0 || __builtin_amdgcn_ballot_w64(npx != 8) == 0;
 
     static_for<0, 2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       float v[24];                                    // the row's 8 px x RGB, normalised
-      if (p.debug_skip & 8) {                       // measurement aid: no accumulation
+      if (MI_DEBUG_SKIP(p) & 8) {                       // measurement aid: no accumulation
 #pragma unroll
         for (int j = 0; j < 24; ++j) v[j] = win[i + 2][(j % 12)] + win[i + (j & 3)][j >> 1];
       } else {
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(THREADS) void tile_kernel(const Params p_in) {
   }
 
   MI_STAMP(6);
-  if (p.debug_skip & 4) {                       // measurement aid: no block reduction
+  if (MI_DEBUG_SKIP(p) & 4) {                       // measurement aid: no block reduction
     if (vmin + vmax + st.slog == 12345.f) p.partials[blockIdx.x] = vmin;
     return;
   }
@@ -862,7 +870,7 @@ static inline int launch(const Params& p, int work_dtype, int pattern, int epi, 
 // dtype with 16-byte aligned rows; 3: u8 / u16 CFA, same dtype out.  All: W % 8 == 0.
 static inline int hot_spec(const Params& p, int work_dtype, int epi) {
   const bool stores = epi == EPI_STORE || epi == EPI_STORE_MINMAX;
-  const bool common = stores && p.debug_skip == 0 && p.W % 8 == 0 && p.vec_store;
+  const bool common = stores && MI_DEBUG_SKIP(p) == 0 && p.W % 8 == 0 && p.vec_store;
   if (!common) return 0;
   const bool unit = p.in_scale == 1.f && p.out_scale == 1.f && p.out_dtype == work_dtype;
   if (unit && (p.src_kind == SRC_PACKED12 || p.src_kind == SRC_PACKED12_IDS) && p.src_fast) return 1;

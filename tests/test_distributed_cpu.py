@@ -1,7 +1,8 @@
-"""world_size-2 gloo test of the sharded metering exchange (taichi_image_amd/distributed.py):
-each rank feeds the partials of ITS frames (produced here by the oracle, standing in for the HIP
-metering passes) through the same collectives the GPU path uses; every rank must end with the
-single-process result over all frames."""
+"""world_size-2 gloo test of the sharded metering exchange (taichi_image_amd/distributed.py): each rank feeds the
+partials of ITS frames (produced here by the oracle, standing in for the HIP metering passes) through the same
+two all-gathers the GPU path uses and combines the gathered rows with the arithmetic of the combine kernels
+(mi_isp_metering_combine_bounds / _sums, mirrored in NumPy below); every rank must end with the single-process
+result over all frames.  The real kernels meet the same check on the GPU in tests/test_distributed_gpu.py."""
 import os
 import socket
 
@@ -12,6 +13,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import isp_oracle as O
+
+f32 = np.float32
 
 
 def _free_port():
@@ -27,26 +30,42 @@ def _frames(n=6):
     return [(rng.random((48, 64, 3), dtype=np.float32) * (0.5 + 0.1 * i)).astype(np.float16) for i in range(n)]
 
 
+def combine_bounds(gathered, prev, alpha):
+    """metering_combine_bounds_kernel: min / max over the ranks, then camera_isp.py:156-157."""
+    lo, hi = f32(gathered[:, 0].min()), f32(gathered[:, 1].max())
+    return np.array([lo + f32(alpha) * (prev[0] - lo), hi + f32(alpha) * (prev[1] - hi)], f32)
+
+
+def combine_sums(gathered, b, prev, alpha):
+    """metering_combine_sums_kernel: camera_isp.py:131-134,164-166 over the ranks' rows."""
+    lmin, lmax = f32(gathered[:, 0].min()), f32(gathered[:, 1].max())
+    sums = gathered[:, 2:7].astype(np.float64).sum(0)
+    n = f32(gathered[:, 7].astype(np.float64).sum())
+    v = np.array([b[0], b[1], lmin, lmax, *(sums.astype(f32) / n)], f32)
+    return (v + f32(alpha) * (prev - v)).astype(f32)
+
+
 def _worker(rank, world, port, steps, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from taichi_image_amd import distributed as D
     group = dist.group.WORLD
-    frames = _frames()
-    mine = frames[rank::world]
-    prev = torch.zeros(9, dtype=torch.float32)
+    assert D.active(group) and D.world_size(group) == world
+    mine = _frames()[rank::world]
+    prev = np.zeros(9, f32)
     alpha = 0.0
     out = []
     for step in range(steps):
         raw = torch.from_numpy(O.metering_partials_bounds(mine))
-        raw = D.allreduce_bounds(raw, group)
-        b = D.blend_bounds(raw, prev, alpha)
-        part, n = O.metering_partials_sums(mine, b.numpy())
+        gathered = D.all_gather_rows(raw, group).numpy()                       # collective 1
+        assert gathered.shape == (world, 2) and np.array_equal(gathered[rank], raw.numpy())
+        b = combine_bounds(gathered, prev, alpha)
+        part, n = O.metering_partials_sums(mine, b)
         part8 = torch.tensor([*part.astype(np.float32), float(n)], dtype=torch.float32)
-        part8 = D.allreduce_sums(part8, group)
-        prev = D.finish_metering(prev, b, part8, alpha)
-        out.append(prev.numpy().copy())
+        gathered8 = D.all_gather_rows(part8, group).numpy()                    # collective 2
+        prev = combine_sums(gathered8, b, prev, alpha)
+        out.append(prev.copy())
         alpha = 0.9
     q.put((rank, np.stack(out)))
     dist.barrier()
@@ -78,6 +97,6 @@ def test_sharded_metering_world2():
 def test_single_process_passthrough():
     from taichi_image_amd import distributed as D
     raw = torch.tensor([0.1, 0.9])
-    assert D.allreduce_bounds(raw, None) is raw
-    part = torch.arange(8, dtype=torch.float32)
-    assert D.allreduce_sums(part, None) is part
+    assert not D.active(None) and D.world_size(None) == 1
+    g = D.all_gather_rows(raw, None)
+    assert g.shape == (1, 2) and torch.equal(g[0], raw)

@@ -219,3 +219,39 @@ def test_whole_frame_kernel_refuses_what_it_cannot_hold(ti, dev):
     big = torch.zeros((3084, 6144), dtype=torch.uint8, device=dev)
     with pytest.raises(RuntimeError, match="whole-frame"):
         pipeline12_reinhard(big, whole_frame=True)
+
+
+# ---- boundary: one C call per camera group (mi_isp_camera_frame_batch), straight through ctypes ------------------
+@pytest.mark.parametrize("tonemap,resize_width", [(0, 0), (0, 960), (1, 960)])
+def test_camera_frame_batch_through_the_c_abi(ti, dev, rng, tonemap, resize_width):
+    """packed bytes of 3 cameras -> u8 outputs with ONE library call per group, over 3 groups (rolling metering):
+    equal to the Python ISP (load_packed12 x n + tonemap_reinhard / tonemap_linear), which the other tests pin."""
+    import ctypes
+    from taichi_image_amd import _native
+    L = _native.lib()
+    H, W, n = 1536, 2048, 3
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.25, resize_width=resize_width, device=dev,
+                      transform=ti.ImageTransform.rotate_90)
+    Wd, Hd = (resize_width, round(H * resize_width / W)) if resize_width else (W, H)
+    scale = resize_width / W if resize_width else 0.0
+    state = torch.zeros(9, dtype=torch.float32, device=dev)
+    images = [torch.empty((Hd, Wd, 3), dtype=torch.float16, device=dev) for _ in range(n)]
+    outs = [torch.empty((Wd, Hd, 3), dtype=torch.uint8, device=dev) for _ in range(n)]      # rotate_90 swaps the dims
+    ws = torch.zeros(int(L.mi_isp_workspace_bytes(Hd, Wd)), dtype=torch.uint8, device=dev)
+    for group in range(3):
+        packs = [torch.from_numpy(natural_packed12(rng, H, W, dark=0.03 * k + 0.02 * group)).to(dev) for k in range(n)]
+        want_imgs = [isp.load_packed12(p) for p in packs]
+        want = (isp.tonemap_reinhard(want_imgs, gamma=0.6, intensity=1.2, light_adapt=0.8, color_adapt=0.1) if tonemap == 0
+                else isp.tonemap_linear(want_imgs, gamma=0.6))
+        alpha = 0.0 if group == 0 else 1.0 - 0.25
+        rc = L.mi_isp_camera_frame_batch(_native.ptr_array(packs), _native.ptr_array(images), _native.ptr_array(outs), n, H, W,
+                                         12, 0, 0, None, ti.types.f16.code, Hd, Wd, ctypes.c_float(scale), 8,
+                                         state.data_ptr(), ctypes.c_float(alpha), tonemap, ctypes.c_float(0.6),
+                                         ctypes.c_float(1.2), ctypes.c_float(0.8), ctypes.c_float(0.1), 1,
+                                         ws.data_ptr(), _native.stream_ptr(dev))
+        assert rc == 0, L.mi_isp_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(state, isp.metrics), f"group {group}: metering state"
+        for k in range(n):
+            assert torch.equal(outs[k], want[k]), f"group {group} camera {k}: u8 output"
+            assert torch.equal(images[k], want_imgs[k]), f"group {group} camera {k}: image left behind"
