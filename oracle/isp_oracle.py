@@ -6,10 +6,25 @@ PARITY STATUS: *parity unpinned* by the reference for everything except the pack
 12-bit encode->decode round trip (the only assertion the reference ships:
 taichi_image/test/packed.py:6-15).  The reference cannot be executed here (its
 ``taichi`` dependency is not installed and cannot be installed), and it ships no golden
-vectors.  This restatement is therefore pinned by (a) that round trip, (b) hand-derived
-known-answer vectors from the reference's bit formulas (tests/golden/kat.json),
-(c) algebraic properties (constant-CFA invariance, channel weight sums == 16, ...) and
-(d) the published Malvar-He-Cutler (2004) filters for the demosaic stage (tests/test_oracle.py).
+vectors.  What pins each stage of this restatement instead (tests/test_oracle.py unless noted):
+
+  stage (reference lines)                         pinned by
+  ----------------------------------------------  ------------------------------------------------------------
+  decode12 / encode12 (packed.py:24-55,92-131)    the reference's round trip; hand KATs of both bit layouts and of
+                                                  the scaled f16 bit patterns (tests/golden/kat.json)
+  weight tables, pattern maps (bayer.py:15-97)    KAT tables; each channel sums to 16; equality with the four
+                                                  published Malvar-He-Cutler 2004 filters (interior, 4 patterns)
+  border renormalisation (bayer.py:138-155)       rebuilt pixel by pixel from the published 5x5 filters on images in
+                                                  which every pixel is a border pixel (4x4, 6x8, 2x6; 4 patterns)
+  bilinear resize (interpolate.py:24-34,59-66)    hand-computed 3x3 -> 2x2 and clamp-to-edge cases; identity / edge
+                                                  properties
+  orientation transforms (interpolate.py:36-54)   group identities
+  ISP Reinhard (camera_isp.py:186-218)            the published photoreceptor model (Reinhard & Devlin 2005, eqs. 1-7,
+                                                  float64) on a 2x2 image with hand-set metering, three parameter sets
+  stateless Reinhard (tonemap.py:108-131)         the same model incl. the (log_min, -log_max) quirk of tonemap.py:102
+  metering (camera_isp.py:142-175)                double-blended bounds and shard-combination properties; the C
+                                                  restatement over three steps (tests/test_c_oracle.py)
+  everything                                      a second, independent implementation (oracle/isp_oracle.c)
 
 Every function cites the reference lines it restates (paths relative to
 /root/reference/taichi_image/).  Arithmetic is carried out in float32 in the same
