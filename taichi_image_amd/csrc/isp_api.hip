@@ -8,6 +8,7 @@
 #include "isp_resize_tile.h"
 #include "isp_stream.h"
 #include "isp_mega.h"
+#include "isp_stream_resize.h"
 #include <mutex>
 
 static thread_local char g_err[512] = "";
@@ -96,6 +97,22 @@ static int packed_params(tile::Params& p, const uint8_t* packed, int H, int W, i
   return 0;
 }
 
+#ifdef MI_STREAM_STAMPS
+// measurement build only: a home for the in-kernel stamps of the kernels that take no workspace (16 words per wave)
+static float* stamp_buffer() {
+  static float* buf = nullptr;
+  if (!buf && hipMalloc(&buf, 4096 * 16 * 4) == hipSuccess) (void)hipMemset(buf, 0, 4096 * 16 * 4);
+  return buf;
+}
+extern "C" int mi_isp_debug_read_stamps(void* host_out, int n_waves) {
+  MI_REQUIRE(host_out && n_waves > 0 && n_waves <= 4096, "debug_read_stamps: bad arguments");
+  MI_HIP(hipDeviceSynchronize());
+  MI_HIP(hipMemcpy(host_out, stamp_buffer(), (size_t)n_waves * 16 * 4, hipMemcpyDeviceToHost));
+  MI_HIP(hipMemset(stamp_buffer(), 0, 4096 * 16 * 4));
+  return 0;
+}
+#endif
+
 // The streaming kernels (isp_stream.h) take the standard 12-bit layout with aligned rows and whole 8-pixel units and
 // store through 16-byte units; everything else stays with the tile kernels.  MI_ISP_MEASURE builds can switch them
 // off (MI_ISP_NO_STREAM=1) to time the tile path.
@@ -118,9 +135,18 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
   p.dst = rgb; p.out_dtype = work_dtype; p.out_scale = 1.f;
   if (scale > 0.f) {
     // unpack -> demosaic -> bilinear fused (isp_resize_tile.h); the caller checks the scale first
+    MI_REQUIRE(Hd > 0 && Wd > 0 && H >= 2 && W >= 2, "load_packed: bad output shape %dx%d", Hd, Wd);
+    if (use_stream(p, work_dtype, nullptr, work_dtype) && rstrm::supported(p, work_dtype, rgb, Hd, Wd, scale, scale)) {
+      rstrm::RSArgs ra = {};
+      ra.t = p; ra.Hd = Hd; ra.Wd = Wd; ra.s0 = scale; ra.s1 = scale;
+      rstrm::geometry(H, W, ra);
+#ifdef MI_STREAM_STAMPS
+      ra.t.partials = stamp_buffer(); ra.t.part_stride = 0;      // this entry point has no workspace: a buffer of the build
+#endif
+      return rstrm::launch(ra, pattern, (hipStream_t)stream);
+    }
     MI_REQUIRE(rtile::scales_fit(scale, scale), "load_packed: scale %g is outside the fused kernel's range "
                "(mi_isp_load_packed_scale_supported); resize separately", (double)scale);
-    MI_REQUIRE(Hd > 0 && Wd > 0 && H >= 2 && W >= 2, "load_packed: bad output shape %dx%d", Hd, Wd);
     rtile::RParams rp = {};
     rp.t = p; rp.Hd = Hd; rp.Wd = Wd; rp.s0 = scale; rp.s1 = scale;
     return rtile::launch(rp, work_dtype, pattern, (hipStream_t)stream);

@@ -408,7 +408,7 @@ MI_DEV void border_fix_rows(float (&v)[24], int rmask, bool is_left, bool is_rig
 #ifdef MI_STREAM_STAMPS
 #define MI_SSTAMP(i)                                                                                          \
   do {                                                                                                        \
-    if (lane == 0 && wave_ok)                                                                                 \
+    if (lane == 0 && wave_ok && p.partials)                                                                   \
       reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride)[g * 16 + (i)] =             \
           (unsigned)__builtin_readcyclecounter();                                                             \
   } while (0)
