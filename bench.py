@@ -203,8 +203,9 @@ def other_workloads(frames, host, device, frames_per_step):
         v = np.rint(v * 0.7 + 0.1 * 4095).astype(np.uint16)
         return pack12(v)
     nonunit = [torch.from_numpy(rescale(host[i % len(host)])).to(device) for i in range(len(frames))]
-    run_batch("config2_bounds_not_unit", nonunit, ALG_BYTES, n_streams=2)
-    # config 2 through the single-launch whole-frame kernel (csrc/isp_mega.h), frames one after the other
+    run_batch("config2_multi_pass_chain_bounds_not_unit", nonunit, ALG_BYTES, n_streams=2)
+    # config 2 through each of the two chains (one of them is the headline)
+    run_batch("config2_multi_pass_chain_2_streams", frames, ALG_BYTES, n_streams=2)
     if whole_frame_fits(H, W, types.f16):
         run_batch("config2_whole_frame_kernel", frames, ALG_BYTES, whole_frame=True)
         run_batch("config2_whole_frame_kernel_bounds_not_unit", nonunit, ALG_BYTES, whole_frame=True)
@@ -234,6 +235,10 @@ def main():
     ap.add_argument("--eager-every", type=int, default=25,
                     help="every n-th step of the timed region is issued launch by launch so that the per-pass "
                          "events (--profile-every) can be recorded (events inside a graph cannot be timed)")
+    ap.add_argument("--chain", default="auto", choices=["auto", "whole-frame", "multi-pass"],
+                    help="config 2 through the single-launch whole-frame kernel (csrc/isp_mega.h; frames one after the "
+                         "other) or through the multi-pass streaming chain (frames on --streams streams); auto = the "
+                         "whole-frame kernel when the frame fits it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2", "isp", "isp-shared-stats"],
@@ -273,7 +278,10 @@ def main():
     host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(n_distinct)]
     frames = [torch.from_numpy(host[i % n_distinct]).to(device) for i in range(args.frames)]
     use_graph = not args.no_graph
-    bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams, use_graph=use_graph)
+    from taichi_image_amd import types as _types
+    from taichi_image_amd.pipeline import whole_frame_fits
+    whole = args.chain == "whole-frame" or (args.chain == "auto" and whole_frame_fits(H, W, _types.f16))
+    bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams, use_graph=use_graph, whole_frame=whole)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -306,13 +314,22 @@ def main():
         total_mp = world * args.frames * args.steps * MP
         value = total_mp / elapsed
         ms_per_step = elapsed / args.steps * 1e3
-        passes = time_passes(frames[0], bp.outputs[0], bp.ws.data_ptr(), device)
         live = [float(v) for v in live_us]            # in-situ averages over the timed region
-        # the dominant kernel: the pass that carries the frame's algorithmic bytes - it reads the packed frame and
-        # writes the output (passes 0-2 only re-read the 18.9 MB packed frame and leave a few hundred bytes)
-        dom = 3
+        if whole:
+            # one kernel per frame: it IS the dominant kernel (reads the packed frame, writes the output)
+            from taichi_image_amd.pipeline import pipeline12_reinhard
+            iso = timed(lambda: pipeline12_reinhard(frames[0], out=bp.outputs[0], whole_frame=True), 100, 10, device) / 100 * 1e6
+            passes = [iso, 0.0, 0.0, 0.0]
+            names = ["mega::frame_kernel<RGGB> (whole chain: unpack + demosaic + statistics + Reinhard + final map, "
+                     "grid barriers inside)", "-", "-", "-"]
+            dom, dom_bytes = 0, ALG_BYTES
+        else:
+            passes = time_passes(frames[0], bp.outputs[0], bp.ws.data_ptr(), device)
+            names = PASS_NAMES
+            # the dominant kernel: the pass that carries the frame's algorithmic bytes - it reads the packed frame and
+            # writes the output (passes 0-2 only re-read the 18.9 MB packed frame and leave a few hundred bytes)
+            dom, dom_bytes = 3, PASS_BYTES[3]
         dom_us = live[dom]
-        dom_bytes = PASS_BYTES[dom]
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         # HBM-side bytes of the dominant kernel: NOT measured by this run - cited from the committed PMC profile
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, scripts/profile_round.sh)
@@ -321,7 +338,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 doc = json.load(open(tpath))
-                traffic = doc["kernels"][f"pass{dom}"]["hbm_bytes"]
+                traffic = doc["kernels"]["whole_frame" if whole else f"pass{dom}"]["hbm_bytes"]
                 traffic_src = "profile-cited, not measured in this run: profiles/traffic_latest.json (" + doc.get("tag", "?") + ")"
             except Exception:
                 traffic = None
@@ -332,7 +349,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config 2: 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap (stateless, "
                                    "gamma 1) -> f16 RGB", "frames_per_rank_per_step": args.frames,
-                       "streams_per_rank": args.streams, "work_dtype": "f16",
+                       "streams_per_rank": 1 if whole else args.streams, "work_dtype": "f16",
+                       "chain": ("whole-frame kernel: one persistent launch per frame (csrc/isp_mega.h), frames one after the "
+                                 "other" if whole else "multi-pass streaming chain (csrc/isp_stream.h), one frame per stream in flight"),
                        "launch": (f"HIP graph replay of the step (captured inside the library); every {args.eager_every}th "
                                   "step launch by launch for the per-pass events" if use_graph else "launch by launch"),
                        "sharding": f"frames x{world}, no collective"},
@@ -340,7 +359,7 @@ def main():
             "timed_region_s": round(elapsed, 3),
             "pipeline_frac_of_hbm_roofline": round(ALG_BYTES * world * args.frames * args.steps / elapsed / 1e9
                                                    / (HBM_PEAK_GBS * world), 4),
-            "roofline": {"bound": "hbm", "kernel": PASS_NAMES[dom],
+            "roofline": {"bound": "hbm", "kernel": names[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_us, 2),
@@ -348,8 +367,9 @@ def main():
                          "isolated_frac": round(dom_bytes / (passes[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "every pass of this chain is bound by instruction throughput (fetch + VALU issue), "
                                  "not by bandwidth: DESIGN.md 5"},
-            "kernels_us_live": {f"pass{k}": round(live[k], 2) for k in range(4)},
-            "kernels_us_isolated": {f"pass{k}": round(passes[k], 2) for k in range(4)},
+            "kernels_us_live": ({"frame_kernel": round(live[0], 2)} if whole else {f"pass{k}": round(live[k], 2) for k in range(4)}),
+            "kernels_us_isolated": ({"frame_kernel": round(passes[0], 2)} if whole else
+                                    {f"pass{k}": round(passes[k], 2) for k in range(4)}),
         }
         if world == 1 and not args.no_other_workloads:
             del bp

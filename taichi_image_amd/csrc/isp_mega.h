@@ -61,6 +61,7 @@ struct MArgs {
   unsigned* sync;                    // partials + SYNC_ROW * part_stride
   unsigned* fpw;                     // FrameParams as words (FP_EXIT2, FP_ERROR)
   unsigned spin_limit;               // polls before a wave gives up (error flag, garbage frame, no hang)
+  unsigned poll_sleep;               // units of 512 cycles between two polls of the barrier counters
 };
 
 MI_DEV float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -128,7 +129,7 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* rows, float* sh_f
       unsigned c = lane < SHARDS ? __hip_atomic_load(shard(m.sync, bar, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       c = (unsigned)wave_sum((float)c);                // <= 2 * CUs: exact in fp32
       if (c >= (unsigned)a.n_blocks) break;
-      __builtin_amdgcn_s_sleep(4);
+      for (unsigned z = 0; z < m.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8);
       if (++spins > m.spin_limit) {                   // a peer is not resident: give up loudly instead of hanging
         if (lane == 0) __hip_atomic_store(m.fpw + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -415,40 +416,51 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   rk.map_key = vgpr(sh_fp[FP_MAPKEY]); rk.ei = vgpr(sh_fp[FP_EI]);
   rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
 
-  // Reinhard of one resident row (tonemap.py:120-131): q[24]
-  auto tone_row = [&](const float (&t)[24], float (&q)[24]) {
-    auto run = [&](auto unit_c, auto ca0_c) {
-      constexpr bool UNIT = decltype(unit_c)::value, CA0 = decltype(ca0_c)::value;
+  // Reinhard of one resident row (tonemap.py:120-131): q[24].  UNIT: bounds exactly (0, 1), the normalisation is the
+  // identity; CA0: color_adapt == 0, one pow per pixel.  The variant is chosen ONCE per phase, outside the row loops: the
+  // executed code of a phase is then one contiguous stretch (the instruction cache is shared by two CUs and a wave's
+  // straight-line code is ~100 KB; interleaved dead variants cost misses).
+  auto tone_row = [&](auto unit_c, auto ca0_c, const float (&t)[24], float (&q)[24]) {
+    constexpr bool UNIT = decltype(unit_c)::value, CA0 = decltype(ca0_c)::value;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float x[3], o[3];
+    for (int k = 0; k < 8; ++k) {
+      float x[3], o[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm01(t[3 * k + ch], lo, inv);
-        reinhard_px<CA0>(x, rk, o);
+      for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm01(t[3 * k + ch], lo, inv);
+      reinhard_px<CA0>(x, rk, o);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) q[3 * k + ch] = o[ch];
-      }
-    };
+      for (int ch = 0; ch < 3; ++ch) q[3 * k + ch] = o[ch];
+    }
+  };
+  auto dispatch = [&](auto&& phase) {
     if (ca0) {
-      if (unit) run(std::true_type{}, std::true_type{});
-      else run(std::false_type{}, std::true_type{});
+      if (unit) phase(std::true_type{}, std::true_type{});
+      else phase(std::false_type{}, std::true_type{});
     } else {
-      run(std::false_type{}, std::false_type{});
+      phase(std::false_type{}, std::false_type{});
     }
   };
 
   // ================================ phase C: bounds of the mapped image (tonemap.py:150-153) ================================
+  // The mapped values of the register-resident rows are KEPT (24 fp32 registers per row take the place of the 12 packed
+  // ones, which phase D no longer needs): phase D then only normalises and stores them, and recomputes Reinhard for
+  // the LDS rows alone.
   vmin = __builtin_inff(); vmax = -__builtin_inff();
+  float qr_[NR][24];
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
     if (r_begin + RR < r_end) {
       float t[24], q[24];
       resident(rrc, t);
-      tone_row(t, q);
+      dispatch([&](auto unit_c, auto ca0_c) { tone_row(unit_c, ca0_c, t, q); });
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         vmin = fminf(vmin, fminf(q[3 * k], fminf(q[3 * k + 1], q[3 * k + 2])));
         vmax = fmaxf(vmax, fmaxf(q[3 * k], fmaxf(q[3 * k + 1], q[3 * k + 2])));
+      }
+      if constexpr (RR >= NL) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) qr_[RR - NL][j] = q[j];
       }
     }
   });
@@ -481,29 +493,45 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   for (int j = 0; j < 6; ++j)
     lane_off[j] = (j * 64 + lane) < active_lanes * units_per_lane ? (uint32_t)(j * 64 + lane) * unit_bytes : INVALID_OFF;
   const uint32_t out_pitch = (uint32_t)p.W * 3u * (uint32_t)osz, band_base = (uint32_t)bx * BAND * 3u * (uint32_t)osz;
-  static_for<0, ROWS>([&](auto rrc) {
+  auto finish_row = [&](auto rrc, float (&q)[24]) {
+    constexpr int RR = decltype(rrc)::value;
+    linear_n<24>(q, lo2, inv2, p.gamma_inv, out_scale);
+    // staging: the LDS slot of a row that has been consumed (its own, or row 0's for the register rows)
+    uint4* stage = xl[wave][RR < NL ? RR : 0];
+    const uint32_t row_base = (uint32_t)(r_begin + RR) * out_pitch + band_base;
+    switch (p.out_dtype) {
+      case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, q); break;
+      case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, q); break;
+      default: {                                        // f16: pairs leave through v_cvt_pk_f16_f32 (half the conversions)
+        uint32_t pk[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[j]) : "v"(q[2 * j]), "v"(q[2 * j + 1]));
+        uint4 mine[3];
+        __builtin_memcpy(mine, pk, sizeof(mine));
+        wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
+        break;
+      }
+    }
+  };
+  // the LDS rows: Reinhard again (their mapped values had no room to stay), then the register rows: only the final map
+  dispatch([&](auto unit_c, auto ca0_c) {
+    static_for<0, NL>([&](auto rrc) {
+      constexpr int RR = decltype(rrc)::value;
+      if (r_begin + RR < r_end) {
+        float t[24], q[24];
+        resident(rrc, t);
+        tone_row(unit_c, ca0_c, t, q);
+        finish_row(rrc, q);
+      }
+    });
+  });
+  static_for<NL, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
     if (r_begin + RR < r_end) {
-      float t[24], q[24];
-      resident(rrc, t);
-      tone_row(t, q);
-      linear_n<24>(q, lo2, inv2, p.gamma_inv, out_scale);
-      // staging: the LDS slot of a row that has been consumed (its own, or row 0's for the register rows)
-      uint4* stage = xl[wave][RR < NL ? RR : 0];
-      const uint32_t row_base = (uint32_t)(r_begin + RR) * out_pitch + band_base;
-      switch (p.out_dtype) {
-        case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, q); break;
-        case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, q); break;
-        default: {                                        // f16: pairs leave through v_cvt_pk_f16_f32 (half the conversions)
-          uint32_t pk[12];
+      float q[24];
 #pragma unroll
-          for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[j]) : "v"(q[2 * j]), "v"(q[2 * j + 1]));
-          uint4 mine[3];
-          __builtin_memcpy(mine, pk, sizeof(mine));
-          wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
-          break;
-        }
-      }
+      for (int j = 0; j < 24; ++j) q[j] = qr_[RR - NL][j];
+      finish_row(rrc, q);
     }
   });
 
