@@ -9,7 +9,7 @@ set -o pipefail
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profile_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --steps 300 > $OUT/trace.log 2>&1 || exit 1
