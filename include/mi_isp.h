@@ -17,8 +17,9 @@
  *    thread is available from mi_isp_last_error();
  *  - `ws_dev` is a scratch buffer of at least mi_isp_workspace_bytes(H, W) bytes, private to
  *    one in-flight call (use one per stream / per frame in flight).  It must be ZERO-FILLED once
- *    before its first use (hipMemset): the whole-frame kernel of mi_isp_pipeline12_reinhard keeps its
- *    grid-barrier counters there and leaves them zero again at the end of every launch.
+ *    before its first use (hipMemset): the whole-frame kernel of mi_isp_pipeline12_reinhard keeps the
+ *    launch count of the workspace and the tagged records of its grid barriers there (a record
+ *    counts when its tag equals the launch count + 1, so stale memory must not look like one).
  */
 #ifndef MI_ISP_H
 #define MI_ISP_H

@@ -1,8 +1,8 @@
 /* TEST INFRASTRUCTURE: exhaustive check of the reciprocal division the streaming kernels use for the border
- * renormalisation at the left / right image edge (csrc/isp_stream.h, div16_by<T>):
+ * renormalisation at the image edges (csrc/isp_stream.h, div16_by<T> and div16_by_rt):
  *     q = a * RN(1/T);  e = fma(-q, T, a);  q' = fma(e, RN(1/T), q)   ==   a / T   (IEEE, round to nearest even)
- * for every finite float a with |a| >= 2^-120 (so that the quotient is a normal number) or a == +0, T in {11, 14, 15, 18, 19} (the in-bounds weight sums of
- * bayer.py:143-149 at a column border).   usage: check_recip_div [stride]   (stride 1 = all 2^32 bit patterns) */
+ * for every finite float a with |a| >= 2^-120 (so that the quotient is a normal number) or a == +0, T in {10..22} \ {16} (every in-bounds weight sum of
+ * bayer.py:143-149 that occurs at a row or column border or in a corner: tile::make_border_table).   usage: check_recip_div [stride]   (stride 1 = all 2^32 bit patterns) */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -10,9 +10,9 @@
 #include <string.h>
 int main(int argc, char** argv) {
   const int64_t stride = argc > 1 ? atoll(argv[1]) : 1;
-  const float ds[] = {11, 14, 15, 18, 19};
+  const float ds[] = {10, 11, 12, 13, 14, 15, 17, 18, 19, 20, 21, 22};
   int rc = 0;
-  for (unsigned k = 0; k < 5; ++k) {
+  for (unsigned k = 0; k < sizeof(ds) / sizeof(ds[0]); ++k) {
     const float d = ds[k], y = 1.0f / d;
     long bad = 0;
 #pragma omp parallel for reduction(+ : bad) schedule(static)

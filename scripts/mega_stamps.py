@@ -16,11 +16,11 @@ out = torch.empty((H, W, 3), dtype=torch.float16, device=dev)
 for _ in range(5): pipeline12_reinhard(frame, out=out, whole_frame=True)
 torch.cuda.synchronize()
 ws = _native.workspace(H, W, dev)
-ws[(64 + 20 * 4096) * 4:].zero_()            # the stamp area only (the sync words must stay as the kernel left them)
-pipeline12_reinhard(frame, out=out, whole_frame=True)
+ws[(64 + 48 * 4096) * 4:].zero_()            # the stamp area only (the sync words must stay as the kernel left them)
+for _ in range(int(os.environ.get('N_B2B', '1'))): pipeline12_reinhard(frame, out=out, whole_frame=True)   # the stamps of the last launch stay
 torch.cuda.synchronize()
 raw = ws.cpu().numpy().view(np.uint32)
-base = 64 + 20 * 4096
+base = 64 + 48 * 4096
 nw = 2048
 s = raw[base:base + nw * 16].reshape(nw, 16).astype(np.int64)
 names = ["entry", "phase A done", "reduced+signalled", "barrier 0 + bounds", "stats folded", "phase C done", "reduced+signalled",
@@ -39,3 +39,49 @@ for name, b0, ref in (("barrier 0", 9, 2), ("barrier 2", 12, 6)):
         d = (s[f][:, [b0, b0 + 1, b0 + 2]] - s[f][:, [ref]]) & 0xFFFFFFFF
         print(name, "folders:", int(f.sum()), " poll matched / partials loaded / published after arrival: mean",
               d.mean(axis=0).astype(int), "p90", np.percentile(d, 90, axis=0).astype(int))
+
+# absolute timeline: needs the stamps library built with -DMI_STAMP_REALTIME (100 MHz counter shared by the chip);
+# with the per-CU cycle counter the rows below are meaningless
+if os.environ.get("STAMP_RT"):
+    t0 = s[:, 0].min()
+    ab = (s[:, :9] - t0) / 100.0
+    print(f"\n{'absolute [us]':24s}    min    p10    p50    p90    max")
+    for i in range(9):
+        a = ab[:, i]
+        print(f"{names[i] if i else 'entry':24s} {a.min():7.2f} {np.percentile(a,10):6.2f} {np.percentile(a,50):6.2f} {np.percentile(a,90):6.2f} {a.max():6.2f}")
+    for name, b0 in (("barrier 0", 9), ("barrier 2", 12)):
+        f = s[:, b0] != 0
+        d = (s[f][:, [b0, b0 + 1, b0 + 2]] - t0) / 100.0
+        print(name, "folding waves: poll matched min/p50/max", np.round(np.percentile(d[:, 0], [0, 50, 100]), 2),
+              " partials loaded", np.round(np.percentile(d[:, 1], [0, 50, 100]), 2), " published", np.round(np.percentile(d[:, 2], [0, 50, 100]), 2))
+    order = np.argsort(ab[:, 2])
+    print("last arrivals at barrier 0 (wave, block, entry, A done, signalled):", [(int(w), int(w // 4), round(ab[w, 0], 2), round(ab[w, 1], 2), round(ab[w, 2], 2)) for w in order[-6:]])
+    order = np.argsort(ab[:, 6])
+    print("last arrivals at barrier 2 (wave, block, C done, signalled):", [(int(w), int(w // 4), round(ab[w, 5], 2), round(ab[w, 6], 2)) for w in order[-6:]])
+if os.environ.get("STAMP_RT"):
+    dur = (ab[:, 1] - ab[:, 0]).reshape(512, 4)
+    print("phase A duration per block [us] (max over its waves): blocks 0,1,2,3:", np.round(dur[:4].max(axis=1), 2), " 508..511:", np.round(dur[508:].max(axis=1), 2),
+          " all blocks p50/p90/max:", np.round(np.percentile(dur.max(axis=1), [50, 90, 100]), 2))
+    slow = np.argsort(dur.max(axis=1))[-8:]
+    print("slowest phase-A blocks:", [(int(b), round(float(dur[b].max()), 2)) for b in slow])
+    durc = (ab[:, 5] - ab[:, 4]).reshape(512, 4)
+    print("phase C duration per block: p50/p90/max", np.round(np.percentile(durc.max(axis=1), [50, 90, 100]), 2), " slowest:", [(int(b), round(float(durc[b].max()), 2)) for b in np.argsort(durc.max(axis=1))[-6:]])
+    sig = (ab[:, 2] - ab[:, 1])
+    print("reduce+post after phase A: p50/p90/p99/max", np.round(np.percentile(sig, [50, 90, 99, 100]), 2), " slowest waves:", [(int(w), int(w // 4), round(float(sig[w]), 2)) for w in np.argsort(sig)[-6:]])
+    hw = s[:, 15].astype(np.int64); xcc = (np.arange(2048) // 4) % 8     # XCC_ID (slot 14, overwritten by a barrier stamp in one wave per block) = block % 8
+    cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3
+    place = (xcc * 64 + se * 16 + sh * 8) * 0 + (xcc << 12 | se << 8 | sh << 4 | cu)     # a CU's id
+    pb = place.reshape(512, 4)
+    print("waves of a block on one CU:", bool((pb == pb[:, :1]).all()), " distinct CUs:", len(set(pb[:, 0].tolist())))
+    from collections import Counter
+    cnt = Counter(pb[:, 0].tolist())
+    print("blocks per CU histogram:", Counter(cnt.values()))
+    for b in (0, 1, 254, 255, 256, 257, 510, 511):
+        mates = [int(x) for x in np.nonzero(pb[:, 0] == pb[b, 0])[0]]
+        print(f"block {b}: xcc {int(xcc[4*b])} se {int(se[4*b])} sh {int(sh[4*b])} cu {int(cu[4*b])} simds {simd[4*b:4*b+4].tolist()}  blocks on this CU: {mates}  phase A {dur[b].max():.2f} us")
+    # phase A duration by XCC
+    for x in range(8):
+        m = xcc.reshape(512, 4)[:, 0] == x
+        print(f"xcc {x}: {int(m.sum())} blocks, phase A p50 {np.percentile(dur.max(axis=1)[m], 50):.2f} max {dur.max(axis=1)[m].max():.2f}")
+    for b in (0, 1, 255, 256, 510, 511):
+        print(f"raw HW_ID / XCC_ID of block {b}:", [f"{int(hw[4*b+w]):08x}/{int(s[4*b+w, 14]):08x}" for w in range(4)])

@@ -26,7 +26,7 @@ for _ in range(5): launch()
 torch.cuda.synchronize()
 cap = 4096
 raw = ws.cpu().numpy().view(np.uint32)
-base = 64 + 20 * cap
+base = 64 + 48 * cap
 nw = int(os.environ.get("MI_ISP_STREAM_WAVES", "2048"))
 s = raw[base:base + nw * 16].reshape(nw, 16).astype(np.int64)
 used = [i for i in range(16) if s[:, i].any()]

@@ -334,10 +334,9 @@ static int pipeline_frame_mega(tile::Params p, strm::SArgs a, int pattern, float
   a.n_px = (float)((int64_t)p.H * p.W); a.intensity = intensity; a.fp_w = ws; a.bounds_post = 2;
   mega::MArgs m = {};
   m.s = a;
-  m.sync = reinterpret_cast<unsigned*>(p.partials + (size_t)mega::SYNC_ROW * p.part_stride);
   m.fpw = reinterpret_cast<unsigned*>(ws);
   m.spin_limit = 100000;                                  // ~100 ms of polling before a wave gives up
-  m.poll_sleep = 8;                                       // 4096 cycles between polls (swept: 70.7 us per frame against 73.3 at 0)
+  m.poll_sleep = 0;                                       // extra 512-cycle naps between two polls (swept: 0 is best)
 #ifdef MI_ISP_MEASURE
   if (getenv("MI_ISP_POLL_SLEEP")) m.poll_sleep = (unsigned)atoi(getenv("MI_ISP_POLL_SLEEP"));
 #endif

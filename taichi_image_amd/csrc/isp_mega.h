@@ -21,13 +21,15 @@
 //   barrier
 //   phase D  Reinhard again, final normalisation, cast, wave-contiguous stores
 //
-// Grid barrier: one agent-scope atomic add per block on a counter of its own 128-byte line, after the
-// block's partial results have been stored write-through (sc1) and waited for; one wave per block polls
-// the counter with sc1 loads (MI355X_MICROARCH.md, cross-workgroup hand-off table, first row), folds all
-// blocks' partials with sc1 loads and hands the scalars to the other waves of its block through LDS.
-// Every block must be resident at once: the host launches at most 2 blocks per CU and refuses larger
-// frames (they take the multi-pass chain); a bounded poll turns a missing peer into an error flag in the
-// workspace instead of a hang.
+// Grid barrier = tagged partial rows, no counters: the last wave of a block stores the block's partial results as
+// 16-byte chunks {3 values, tag} write-through (sc1) and goes on; tag = the launch count of the workspace + 1.  One
+// wave per block polls the chunks of ALL blocks with sc1 loads (one aligned 16-byte load returns values and tag
+// together) until every tag matches, folds them in block order - identical arithmetic in every block - and hands
+// the scalars to the other waves of its block through LDS.  Against the counter design (store, wait for the
+// write-through, atomic add; poll the counters, then load the partials) two of the four dependent memory round trips
+// after the last arrival are gone.  Every block must be resident at once: the host launches at most 2 blocks per CU
+// and refuses larger frames (they take the multi-pass chain); a bounded poll turns a missing peer into an error flag
+// in the workspace instead of a hang.
 #pragma once
 #include "isp_stream.h"
 
@@ -42,37 +44,37 @@ constexpr int NL = 5;                // of which live in LDS ...
 constexpr int NR = ROWS - NL;        // ... and in registers
 constexpr int ROW_U4 = 64 * 3;       // one f16 row of a wave: 64 lanes x 3 x 16 B
 
-// Sync words (uint32) in the workspace.  Atomic adds to ONE address serialise at the memory side (~40 ns each: 512
-// arrivals on one counter cost 15-20 us, measured), so every counter is kept as 32 shards, each on a 128-byte line
-// of its own; block b adds to shard b % 32 and a poller reads all 32 shards with one wave instruction.
-// Partial row 11 (unused by the passes, 4096 words) holds the shards of the three barriers and of the exit count;
-// two more words live in unused FrameParams slots.
-constexpr int SYNC_ROW = 11, SYNC_STRIDE = 32, SHARDS = 32;
-enum { SY_BAR0 = 0, SY_BAR1 = 1, SY_BAR2 = 2, SY_EXIT = 3 };
-// Phase B's statistics go to rows of their own: the speculative ones (rows 2..8) were read by every block at barrier 0,
-// and an sc1 load is served by the reader's L2 - a second read of a line another XCD has rewritten since may be stale.
-// Every partial row is therefore written once and read only after the barrier that follows its writing.
-constexpr int ROW_STATS_B = 12;
-constexpr int FP_EXIT2 = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
-MI_DEV unsigned* shard(unsigned* sync, int bar, int k) { return sync + (size_t)(bar * SHARDS + k) * SYNC_STRIDE; }
+// Tagged partial rows of the three barriers, behind the rows of the multi-pass chain (strm::MEGA_ROW_BASE): every barrier
+// owns 8 partial rows (>= 128 KB: part_stride >= 4096), block b's record is the REC bytes at byte offset b * REC of that
+// area and chunk c of its ceil(NV / 3) chunks the 16 bytes at + 16 c.  One record per 256-byte block of memory: 512
+// pollers read every record several times, and packed records (8 KB for all of them) would queue on one or two
+// memory channels.  A record is written once per launch and polled until its tags match; the tag of a launch is
+// FP_EPOCH + 1, and block 0 advances FP_EPOCH as its last action (every block has read it long before: it has passed
+// all barriers by then).  The workspace must be zero-filled once (include/mi_isp.h): tag 1 of the first launch then
+// never matches stale memory.
+#ifndef MI_MEGA_REC
+#define MI_MEGA_REC 256
+#endif
+constexpr int REC = MI_MEGA_REC;
+constexpr int MROW_BAR0 = strm::MEGA_ROW_BASE, MROW_BAR1 = MROW_BAR0 + 8, MROW_BAR2 = MROW_BAR1 + 8;
+static_assert(MROW_BAR2 + 8 <= strm::PART_ROWS, "the whole-frame kernel's rows must fit the workspace");
+static_assert(REC >= 48 && REC % 16 == 0, "three 16-byte chunks per record");
+constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
 
 struct MArgs {
   SArgs s;
-  unsigned* sync;                    // partials + SYNC_ROW * part_stride
-  unsigned* fpw;                     // FrameParams as words (FP_EXIT2, FP_ERROR)
+  unsigned* fpw;                     // FrameParams as words (FP_EPOCH, FP_ERROR)
   unsigned spin_limit;               // polls before a wave gives up (error flag, garbage frame, no hang)
-  unsigned poll_sleep;               // units of 512 cycles between two polls of the barrier counters
+  unsigned poll_sleep;               // units of 512 cycles between two polls of the partial rows
 };
 
-MI_DEV float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-MI_DEV void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// The block's contribution to a grid-wide reduction, then its arrival at barrier `bar`: every wave reduces in
-// registers and leaves its row in LDS; the wave that arrives last combines the rows in wave order, stores the block's
-// partial write-through, waits for the stores and signals with one atomic add.  No workgroup barrier.
+// The block's contribution to a grid-wide reduction = its arrival at the barrier: every wave reduces in registers and
+// leaves its row in LDS; the wave that arrives last combines the rows in wave order and stores the block's chunks
+// {3 values, tag} write-through.  No wait, no counter, no workgroup barrier.
 template <int NV>
-MI_DEV void block_reduce_signal(const float (&v)[NV], const int (&op)[NV], float (*red)[16], unsigned* arrived,
-                                float* partials, int stride, int block, int wave, int lane, unsigned* counter) {
+MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (*red)[16], unsigned* arrived,
+                              float* area, int stride, int block, int wave, int lane, uint32_t tag) {
+  constexpr int NCH = (NV + 2) / 3;
   float r[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) r[k] = op[k] == 0 ? wave_min(v[k]) : (op[k] == 1 ? wave_max(v[k]) : wave_sum(v[k]));
@@ -84,7 +86,8 @@ MI_DEV void block_reduce_signal(const float (&v)[NV], const int (&op)[NV], float
   }
   before = __builtin_amdgcn_readfirstlane(before);
   if ((before & (WAVES - 1)) == WAVES - 1) {          // wave-uniform: this wave arrived last (the count runs on over the phases)
-    float mine = 0.f;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 mine = {0u, 0u, 0u, tag};                       // lane c holds chunk c
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       float x = red[0][k];
@@ -93,108 +96,167 @@ MI_DEV void block_reduce_signal(const float (&v)[NV], const int (&op)[NV], float
         const float o = red[w][k];
         x = op[k] == 0 ? fminf(x, o) : (op[k] == 1 ? fmaxf(x, o) : x + o);
       }
-      mine = lane == k ? x : mine;
+      if (lane == k / 3) mine[k % 3] = __builtin_bit_cast(uint32_t, x);
     }
-    if (lane < NV) st_sc1(partials + (size_t)lane * stride + block, mine);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the block's shard
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(area, 0, (int)((size_t)8 * stride * sizeof(float)), 0x00020000);
+    const uint32_t off = lane < NCH ? (uint32_t)block * REC + 16u * lane : INVALID_OFF;
+    __builtin_amdgcn_raw_buffer_store_b128(mine, rs, off, 0, 16);      // aux 16 = sc1: write-through, visible to the other XCDs
   }
 }
 
-// four consecutive partials with one sc1 load (a buffer load the compiler can track: an asm load would hand its
-// destination registers back to the allocator while the data is still in flight).  aux 16 = sc1 on gfx950.
-MI_DEV float4 ld_sc1_x4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-  const u4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
-  return float4{__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y), __builtin_bit_cast(float, r.z),
-                __builtin_bit_cast(float, r.w)};
-}
+// LDS of the barrier folds: per barrier a ticket that hands out the roles, the partial folds of the four roles, a count
+// of the roles that are done and the flag the block waits for.
+struct FoldLds {
+  unsigned ticket[4], done[4], flag[4];
+  float mm[WAVES][4];
+  double sum[WAVES][5];
+};
 
-// Wait for barrier `bar` and derive the scalars of the next phase.  The first wave of the block to get here polls the
-// 32 counter shards (one sc1 load per lane), folds the partial rows of all blocks (identical arithmetic in every
-// block) and publishes the scalars in LDS; the other waves of the block wait for its LDS flag.
-// NROWS partial rows starting at `rows`: 2 = {min, max}; 7 = statistics; 9 = bounds followed by the speculative
-// statistics (folded together: the statistics are finalized only when the bounds turn out to be (0, 1)).
-template <int NROWS, int FIN>
-MI_DEV void barrier_fold(const MArgs& m, int bar, const float* rows, float* sh_fp, unsigned* ticket, unsigned* flag,
-                         int lane, unsigned* stamps = nullptr) {
+// Wait for the barrier whose records live in `area` and derive the scalars of the next phase.  Every wave of the block
+// takes a role r = its arrival order at this barrier and owns the records of blocks [128 r, 128 r + 128), two per lane:
+// it polls all their chunks (6 loads in flight, only the chunks still missing are asked for again: an out-of-range
+// offset makes no memory request), folds them in block order and leaves the partial fold in LDS; the role that finishes
+// last combines the four partial folds in role order - identical arithmetic in every block - and publishes the scalars.
+// NV values per block: 2 = {min, max}; 7 = statistics; 9 = bounds followed by the speculative statistics (finalized
+// only when the bounds turn out to be (0, 1)).
+// Plain sc1 buffer loads (aux 16), compiler-visible: an asm load would hand its destination registers back to the
+// allocator while the data is still in flight (that was a memory fault), and atomic loads are waited for one by one.
+template <int NV, int FIN>
+MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t tag, float* sh_fp, FoldLds& fl, int lane,
+                         bool rgb_sums = true, unsigned* stamps = nullptr) {
   const SArgs& a = m.s;
-  unsigned t = 0;
-  if (lane == 0) t = __hip_atomic_fetch_add(ticket + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  t = __builtin_amdgcn_readfirstlane(t);
-  if (t == 0) {
-    // ---- this wave folds for its block ----
-    unsigned spins = 0;
-    for (;;) {
-      unsigned c = lane < SHARDS ? __hip_atomic_load(shard(m.sync, bar, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      c = (unsigned)wave_sum((float)c);                // <= 2 * CUs: exact in fp32
-      if (c >= (unsigned)a.n_blocks) break;
-      for (unsigned z = 0; z < m.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8);
-      if (++spins > m.spin_limit) {                   // a peer is not resident: give up loudly instead of hanging
-        if (lane == 0) __hip_atomic_store(m.fpw + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
+  constexpr int NCH = (NV + 2) / 3;
+  constexpr int NMM = NV == 9 ? 4 : 2;                // leading min / max values (alternating)
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  unsigned role = 0;
+  if (lane == 0) role = __hip_atomic_fetch_add(fl.ticket + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  role = __builtin_amdgcn_readfirstlane(role);
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(area), 0, (int)((size_t)8 * a.t.part_stride * sizeof(float)), 0x00020000);
+  u4 v[2][NCH];
+  bool have[2][NCH];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      v[u][c] = u4{0u, 0u, 0u, 0u};
+      // the per-channel sums are the last chunk: nobody posted any when color_adapt == 0 (wave-uniform), skip it
+      have[u][c] = (int)role * 128 + u * 64 + lane >= a.n_blocks || (NV >= 7 && c == NCH - 1 && !rgb_sums);
     }
-    if (stamps && lane == 0) stamps[0] = (unsigned)__builtin_readcyclecounter();
-    constexpr int NMM = NROWS == 9 ? 4 : 2;           // leading min / max rows (alternating)
-    float mm[NMM];
-    double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  unsigned spins = 0;
+  // Stage 0: watch ONE record - the last block's, which is dispatched last and (measured) posts last - with one lane
+  // until it is there.  2048 waves polling all records while others are still in their phase slow those down (their
+  // loads and posts queue behind the polls: the last blocks' phase A ran 4 us long); one request per wave and round
+  // does not.  Any other late block is waited for by stage 1.
+  for (;;) {
+    const uint32_t off = lane == 0 ? (uint32_t)(a.n_blocks - 1) * REC + 12u : INVALID_OFF;
+    const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, 16);
+    if (__builtin_amdgcn_readfirstlane(t) == tag) break;
+    for (unsigned z = 0; z <= m.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8);
+    if (++spins > m.spin_limit) break;                // stage 1 raises the error
+  }
+  // Stage 1: all records of this role
+  for (;;) {
 #pragma unroll
-    for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
-    // plain sc1 buffer loads (aux 16), not atomic loads: the compiler waits for an atomic load at once, and 72
-    // serialised round trips cost 24k cycles here (measured); these are issued together, one wait per round
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(rows), 0, (int)((size_t)NROWS * a.t.part_stride * sizeof(float)), 0x00020000);
-    for (int base = 0; base < a.n_blocks; base += 256) {      // four blocks per lane and round, all rows in flight together
-      float v[4][NROWS];
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = base + u * 64 + lane;
+      for (int c = 0; c < NCH; ++c) {
+        const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)((int)role * 128 + u * 64 + lane) * REC + 16u * c;
+        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, 16);
+        v[u][c] = have[u][c] ? v[u][c] : t;
+      }
+    bool all = true;
 #pragma unroll
-        for (int k = 0; k < NROWS; ++k) {
-          const uint32_t off = i < a.n_blocks ? (uint32_t)((size_t)k * a.t.part_stride + i) * 4u : INVALID_OFF;
-          v[u][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, 16));
-          if (i >= a.n_blocks) v[u][k] = k < NMM ? ((k & 1) ? -__builtin_inff() : __builtin_inff()) : 0.f;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) { have[u][c] = have[u][c] || v[u][c].w == tag; all = all && have[u][c]; }
+    const unsigned long long missing = __builtin_amdgcn_ballot_w64(!all);
+    if (missing == 0) break;
+    // many records missing: the phase is still running elsewhere, poll rarely; few: the last arrivals, poll at once
+    const unsigned naps = __builtin_popcountll(missing) > 16 ? 4u * m.poll_sleep + 1u : m.poll_sleep;
+    for (unsigned z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
+    if (++spins > m.spin_limit) {                     // a peer is not resident: give up loudly instead of hanging
+      if (lane == 0) __hip_atomic_store(m.fpw + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  if (stamps && lane == 0 && role == 0) stamps[0] = MI_STAMP_NOW();
+  float mm[NMM];
+  double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const bool real = (int)role * 128 + u * 64 + lane < a.n_blocks;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint32_t w3[3] = {v[u][c].x, v[u][c].y, v[u][c].z};   // (element access by a loop index was miscompiled)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int k = 3 * c + e;
+        if (k < NV) {
+          const float x = __builtin_bit_cast(float, w3[e]);
+          if (k < NMM) { if (real) mm[k] = (k & 1) ? fmaxf(mm[k], x) : fminf(mm[k], x); }
+          else sum[k - NMM] += real ? (double)x : 0.0;
         }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < NROWS; ++k) {
-          if (k < NMM) mm[k] = (k & 1) ? fmaxf(mm[k], v[u][k]) : fminf(mm[k], v[u][k]);
-          else sum[k - NMM] += (double)v[u][k];
-        }
     }
-    if (stamps && lane == 0) stamps[1] = (unsigned)__builtin_readcyclecounter();
-    double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  }
 #pragma unroll
-    for (int k = 0; k < NMM; ++k) tot[k] = (double)((k & 1) ? wave_max(mm[k]) : wave_min(mm[k]));
-    if (NROWS >= 7) {
+  for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? wave_max(mm[k]) : wave_min(mm[k]);
+  if (NV >= 7) {
+    sum[0] = wave_sum(sum[0]); sum[1] = wave_sum(sum[1]);
+    if (rgb_sums) {                                    // else they are zero
 #pragma unroll
-      for (int k = 0; k < 5; ++k) tot[NMM + k] = wave_sum(sum[k]);
+      for (int k = 2; k < 5; ++k) sum[k] = wave_sum(sum[k]);
     }
+  }
+  unsigned finished = 0;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NMM; ++k) fl.mm[role][k] = mm[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) fl.sum[role][k] = sum[k];
+    finished = __hip_atomic_fetch_add(fl.done + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  finished = __builtin_amdgcn_readfirstlane(finished);
+  if (stamps && lane == 0 && role == 0) stamps[1] = MI_STAMP_NOW();
+  if (finished == WAVES - 1) {
+    // ---- the last role combines the partial folds (role order) and publishes the scalars ----
     if (lane == 0) {
+      double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NMM; ++k) {
+        float x = fl.mm[0][k];
+#pragma unroll
+        for (int r = 1; r < WAVES; ++r) x = (k & 1) ? fmaxf(x, fl.mm[r][k]) : fminf(x, fl.mm[r][k]);
+        tot[k] = (double)x;
+      }
+      if (NV >= 7) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) tot[NMM + k] = ((fl.sum[0][k] + fl.sum[1][k]) + fl.sum[2][k]) + fl.sum[3][k];
+      }
       ew::FinArgs fa = {};
       fa.fp = sh_fp; fa.n_px = a.n_px; fa.intensity = a.intensity; fa.la = a.t.la; fa.ca = a.t.ca;
       fa.bounds_post = a.bounds_post;
-      if constexpr (NROWS == 9) {
+      if constexpr (NV == 9) {
         ew::finalize_scalars<true>(ew::FIN_BOUNDS, fa, tot);
         if (sh_fp[FP_LO] == 0.f && sh_fp[FP_INV] == 1.f) ew::finalize_scalars<true>(ew::FIN_STATS, fa, tot + 2);
       } else {
         ew::finalize_scalars<true>(FIN, fa, tot);
       }
-      if (stamps) stamps[2] = (unsigned)__builtin_readcyclecounter();
-      __hip_atomic_store(flag + bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (stamps) stamps[2] = MI_STAMP_NOW();
+      __hip_atomic_store(fl.flag + bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       // block 0 leaves the frame's scalars in FrameParams, as the multi-pass chain does (callers may read them back)
       if (blockIdx.x == 0 && a.fp_w) {
         for (int i = 0; i <= FP_MAXOUT; ++i) a.fp_w[i] = sh_fp[i];
       }
     }
   } else {
-    unsigned spins = 0;
-    while (__hip_atomic_load(flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+    unsigned naps = 0;
+    while (__hip_atomic_load(fl.flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > 64u * m.spin_limit) break;
+      if (++naps > 64u * m.spin_limit) break;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -219,8 +281,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   __shared__ float lut[4096];
   __shared__ float red[WAVES][16];
   __shared__ float sh_fp[FP_COUNT];
-  __shared__ unsigned arrived, ticket[4], flag[4];
-  if (threadIdx.x < 4) { ticket[threadIdx.x] = 0; flag[threadIdx.x] = 0; }
+  __shared__ unsigned arrived;
+  __shared__ FoldLds fl;
+  if (threadIdx.x < 4) { fl.ticket[threadIdx.x] = 0; fl.done[threadIdx.x] = 0; fl.flag[threadIdx.x] = 0; }
   if (threadIdx.x == 0) arrived = 0;
   if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = 0.f;
 
@@ -249,7 +312,16 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
     d[3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ext_off + row_off, 0, 0);
   };
 
+  const uint32_t epoch = __builtin_amdgcn_readfirstlane(m.fpw[FP_EPOCH]);
+  const uint32_t tag = epoch + 1u == 0u ? 1u : epoch + 1u;     // never 0: a zero-filled workspace matches no launch
   MI_SSTAMP(0);
+#ifdef MI_STREAM_STAMPS                                  // where the wave runs: HW_ID (SE / CU / SIMD / slot) and XCC_ID
+  if (lane == 0 && wave_ok && p.partials) {
+    unsigned* st_ = reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16;
+    st_[15] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    st_[14] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+  }
+#endif
   // ================================ phase A: demosaic once ================================
   float wq[8];
 #pragma unroll
@@ -339,16 +411,15 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   });
 
   MI_SSTAMP(1);
-  float* rows_bounds = p.partials + (size_t)ROW_BOUNDS * p.part_stride;
-  float* rows_stats = p.partials + (size_t)ROW_STATS_B * p.part_stride;
-  float* rows_bounds2 = p.partials + (size_t)ROW_BOUNDS2 * p.part_stride;
+  float* rows_bounds = p.partials + (size_t)MROW_BAR0 * p.part_stride;
+  float* rows_stats = p.partials + (size_t)MROW_BAR1 * p.part_stride;
+  float* rows_bounds2 = p.partials + (size_t)MROW_BAR2 * p.part_stride;
   {
     st.finish();
     if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }
     const float v9[9] = {vmin, vmax, st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[9] = {0, 1, 0, 1, 2, 2, 2, 2, 2};
-    block_reduce_signal<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane,
-                           shard(m.sync, SY_BAR0, blockIdx.x % SHARDS));
+    block_reduce_post<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane, tag);
   }
 
   // the resident row RR as 24 fp32 values
@@ -370,10 +441,10 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   // ================================ barrier 0: bounds (tonemap.py:146) ================================
   MI_SSTAMP(2);
 #ifdef MI_STREAM_STAMPS
-  barrier_fold<9, ew::FIN_BOUNDS>(m, SY_BAR0, rows_bounds, sh_fp, ticket, flag, lane,
+  barrier_fold<9, ew::FIN_BOUNDS>(m, 0, rows_bounds, tag, sh_fp, fl, lane, want_rgb,
                                   reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16 + 9);
 #else
-  barrier_fold<9, ew::FIN_BOUNDS>(m, SY_BAR0, rows_bounds, sh_fp, ticket, flag, lane);
+  barrier_fold<9, ew::FIN_BOUNDS>(m, 0, rows_bounds, tag, sh_fp, fl, lane, want_rgb);
 #endif
   MI_SSTAMP(3);
   const float lo_s = sh_fp[FP_LO], inv_s = sh_fp[FP_INV];
@@ -398,17 +469,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
     if (!col_ok) st.init();
     const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[7] = {0, 1, 2, 2, 2, 2, 2};
-    block_reduce_signal<7>(v7, op, red, &arrived, rows_stats, p.part_stride, blockIdx.x, wave, lane,
-                           shard(m.sync, SY_BAR1, blockIdx.x % SHARDS));
-    barrier_fold<7, ew::FIN_STATS>(m, SY_BAR1, rows_stats, sh_fp, ticket, flag, lane);
+    block_reduce_post<7>(v7, op, red, &arrived, rows_stats, p.part_stride, blockIdx.x, wave, lane, tag);
+    barrier_fold<7, ew::FIN_STATS>(m, 1, rows_stats, tag, sh_fp, fl, lane);
   }
-#if 0
-  else {
-    // the speculative statistics of phase A are the real ones: fold them (no further barrier: they were
-    // published together with the bounds)
-    barrier_fold<ew::FIN_STATS>(m, SY_BAR0, rows_stats, sh_fp, ticket + 1 - SY_BAR0, flag + 1 - SY_BAR0, lane);
-  }
-#endif
   MI_SSTAMP(4);
   ReinhardK rk;
   const bool ca0 = p.ca == 0.f;
@@ -469,15 +532,14 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
     if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); }
     const float v2[2] = {vmin, vmax};
     const int op[2] = {0, 1};
-    block_reduce_signal<2>(v2, op, red, &arrived, rows_bounds2, p.part_stride, blockIdx.x, wave, lane,
-                           shard(m.sync, SY_BAR2, blockIdx.x % SHARDS));
+    block_reduce_post<2>(v2, op, red, &arrived, rows_bounds2, p.part_stride, blockIdx.x, wave, lane, tag);
   }
   MI_SSTAMP(6);
 #ifdef MI_STREAM_STAMPS
-  barrier_fold<2, ew::FIN_BOUNDS2>(m, SY_BAR2, rows_bounds2, sh_fp, ticket, flag, lane,
+  barrier_fold<2, ew::FIN_BOUNDS2>(m, 2, rows_bounds2, tag, sh_fp, fl, lane, true,
                                    reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16 + 12);
 #else
-  barrier_fold<2, ew::FIN_BOUNDS2>(m, SY_BAR2, rows_bounds2, sh_fp, ticket, flag, lane);
+  barrier_fold<2, ew::FIN_BOUNDS2>(m, 2, rows_bounds2, tag, sh_fp, fl, lane);
 #endif
   MI_SSTAMP(7);
   const float lo2 = vgpr(sh_fp[FP_LO2]), inv2 = vgpr(sh_fp[FP_INV2]);
@@ -536,26 +598,8 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   });
 
   MI_SSTAMP(8);
-  // the last block to leave zeroes the sync words for the next launch on this workspace (a two-level count: the
-  // blocks of a shard, then the shards)
-  unsigned before = 0;
-  if (lane == 0) before = __hip_atomic_fetch_add(&arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  before = __builtin_amdgcn_readfirstlane(before);
-  if ((before & (WAVES - 1)) == WAVES - 1) {
-    const int k = blockIdx.x % SHARDS;
-    const unsigned in_shard = ((unsigned)a.n_blocks - (unsigned)k + SHARDS - 1) / SHARDS;
-    const unsigned used = (unsigned)a.n_blocks < (unsigned)SHARDS ? (unsigned)a.n_blocks : (unsigned)SHARDS;
-    unsigned last = 0;
-    if (lane == 0) {
-      if (__hip_atomic_fetch_add(shard(m.sync, SY_EXIT, k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1)
-        last = __hip_atomic_fetch_add(m.fpw + FP_EXIT2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1;
-    }
-    if (__builtin_amdgcn_readfirstlane(last)) {
-      for (int i = lane; i < 4 * SHARDS; i += 64)
-        __hip_atomic_store(m.sync + (size_t)i * SYNC_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane == 0) __hip_atomic_store(m.fpw + FP_EXIT2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  // the launch count of the workspace: every block read it at entry and has passed all barriers before block 0 gets here
+  if (blockIdx.x == 0 && threadIdx.x == 0) m.fpw[FP_EPOCH] = epoch + 1u;
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -568,7 +612,8 @@ static inline bool geometry(int H, int W, int n_cus, SArgs& a) {
   const int bands_y = (H + ROWS - 1) / ROWS;
   a.n_waves = a.bands_x * bands_y;
   a.n_blocks = (a.n_waves + WAVES - 1) / WAVES;
-  return a.n_blocks <= 2 * n_cus;
+  // all blocks resident (2 per CU) and their records inside the 8 partial rows of a barrier (part_stride >= 4096)
+  return a.n_blocks <= 2 * n_cus && (size_t)a.n_blocks * REC <= (size_t)8 * 4096 * sizeof(float);
 }
 
 int launch_rggb(const MArgs& m, hipStream_t stream);

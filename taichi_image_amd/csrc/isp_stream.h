@@ -51,8 +51,9 @@ enum Epi {
 //   S_BOUNDS / S_STORE_BOUNDS: rows 0,1 = min,max; rows 2..8 = gmin,gmax,slog2,sgray,s0,s1,s2 (speculative)
 //   S_STATS:                   rows 2..8 (overwrites the speculative ones)
 //   S_RH_MINMAX:               rows 9,10
-constexpr int ROW_BOUNDS = 0, ROW_STATS = 2, ROW_BOUNDS2 = 9, PART_ROWS = 20;
-// (rows 11 and 12..18 belong to the whole-frame kernel, isp_mega.h: sync words, second statistics)
+constexpr int ROW_BOUNDS = 0, ROW_STATS = 2, ROW_BOUNDS2 = 9;
+// rows 20..47: the tagged rows of the whole-frame kernel's grid barriers (isp_mega.h)
+constexpr int MEGA_ROW_BASE = 20, PART_ROWS = 48;
 
 struct SArgs {
   Params t;
@@ -329,8 +330,6 @@ MI_DEV void pull(const SArgs& a, const float* rows, float* sh_fp, double (*sh_to
   __syncthreads();
 }
 
-// the in-bounds weight sums in the constant address space: uniform indices become scalar loads
-__constant__ const tile::BorderTable BORDER_TC = tile::make_border_table();
 
 // ---- border renormalisation (bayer.py:143-155): v = acc * 16 / t for the pixels whose 13-tap diamond leaves the
 // image, t = the in-bounds weight sum (tile::BORDER_T).  No vector-memory lookups here: a load in this path would
@@ -376,26 +375,66 @@ MI_DEV void border_fix_cols(float (&v)[24], bool is_left, bool is_right, bool an
   }
 }
 
-// the image's first and last two rows (rmask != 31, wave-uniform): every pixel of the row is renormalised; the sums
-// come from the table through scalar loads (uniform index), one per lane kind
+// {T, RN(1/T)} per [kernel][row mask slot][column mask slot][channel], masks in the order {31, 28, 30, 15, 7} (inside,
+// offsets -2 -1 outside, -2 outside, +2 outside, +1 +2 outside): the only masks an image of at least 4 rows and
+// columns has.  A uniform slot index makes every access a scalar load, and no load depends on another.
+struct DY { float d, y; };
+struct BorderDY { DY t[4][5][5][3]; };
+constexpr BorderDY make_border_dy() {
+  constexpr int MASKS[5] = {31, 28, 30, 15, 7};
+  constexpr tile::BorderTable b = tile::make_border_table();
+  BorderDY r = {};
+  for (int k = 0; k < 4; ++k)
+    for (int ri = 0; ri < 5; ++ri)
+      for (int ci = 0; ci < 5; ++ci)
+        for (int ch = 0; ch < 3; ++ch) {
+          const int T = (int)(int8_t)(b.t[k][MASKS[ri]][MASKS[ci]] >> (8 * ch));
+          r.t[k][ri][ci][ch].d = (float)T;
+          r.t[k][ri][ci][ch].y = 1.0f / (float)T;     // 10 <= T <= 22 (static_assert below)
+        }
+  return r;
+}
+constexpr bool border_dy_in_range() {
+  constexpr BorderDY r = make_border_dy();
+  for (int k = 0; k < 4; ++k)
+    for (int ri = 0; ri < 5; ++ri)
+      for (int ci = 0; ci < 5; ++ci)
+        for (int ch = 0; ch < 3; ++ch)
+          if (r.t[k][ri][ci][ch].d < 10.f || r.t[k][ri][ci][ch].d > 22.f) return false;
+  return true;
+}
+static_assert(border_dy_in_range(), "a weight sum outside the range oracle/check_recip_div.c checks");
+__constant__ const BorderDY BORDER_DY = make_border_dy();
+
+// div16_by<T> with the divisor in registers: d = T, y = RN(1/T) (same arithmetic, same exhaustive check)
+MI_DEV float div16_by_rt(float x, float d, float y) {
+  const float a = x * 16.f;
+  const float q = a * y;
+  const float e = __builtin_fmaf(-q, d, a);
+  return __builtin_fmaf(e, y, q);
+}
+
+// the image's first and last two rows (rmask != 31, wave-uniform): every pixel of the row is renormalised.  Divisor
+// and reciprocal come from BORDER_DY through scalar loads (uniform slot), one pair per lane kind, and the division is
+// the reciprocal sequence of div16_by: 24 IEEE divisions per row made the border bands the last to finish their
+// phase (+2.5 us on the whole-frame kernel's first barrier).
 template <int PR, int PC, int I>
 MI_DEV void border_fix_rows(float (&v)[24], int rmask, bool is_left, bool is_right) {
+  const int rs = __builtin_amdgcn_readfirstlane(rmask == 28 ? 1 : rmask == 30 ? 2 : rmask == 15 ? 3 : rmask == 7 ? 4 : 0);
+  // rs > 0 for every border row of an image with at least 4 rows (strm::supported refuses smaller ones)
   static_for<0, 8>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     constexpr int KIDX = ((I + PR) & 1) + 2 * ((k + PC) & 1);
-    constexpr int cl = k == 0 ? 28 : k == 1 ? 30 : 31, cr = k == 6 ? 15 : k == 7 ? 7 : 31;
-    // three uniform (scalar) loads, then per-lane selects: a select between two table ADDRESSES would become a
-    // per-lane vector load
-    const uint32_t t_mid = __builtin_amdgcn_readfirstlane(BORDER_TC.t[KIDX][rmask][31]);
-    const uint32_t t_l = __builtin_amdgcn_readfirstlane(BORDER_TC.t[KIDX][rmask][cl]);
-    const uint32_t t_r = __builtin_amdgcn_readfirstlane(BORDER_TC.t[KIDX][rmask][cr]);
-    uint32_t tq = t_mid;
-    if constexpr (cl != 31) tq = is_left ? t_l : tq;
-    if constexpr (cr != 31) tq = is_right ? t_r : tq;
+    constexpr int cs = k == 0 ? 1 : k == 1 ? 2 : k == 6 ? 3 : k == 7 ? 4 : 0;     // this pixel's border slot, if any
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float t = (float)(int)(int8_t)(tq >> (8 * ch));
-      v[3 * k + ch] = (v[3 * k + ch] * 16.f) / t;     // t == 16: the value itself
+      float d = BORDER_DY.t[KIDX][rs][0][ch].d, y = BORDER_DY.t[KIDX][rs][0][ch].y;
+      if constexpr (cs != 0) {
+        const bool mine = cs <= 2 ? is_left : is_right;
+        d = mine ? BORDER_DY.t[KIDX][rs][cs][ch].d : d;
+        y = mine ? BORDER_DY.t[KIDX][rs][cs][ch].y : y;
+      }
+      v[3 * k + ch] = div16_by_rt(v[3 * k + ch], d, y);
     }
   });
 }
@@ -406,14 +445,20 @@ MI_DEV void border_fix_rows(float (&v)[24], int rmask, bool is_left, bool is_rig
 // measurement aid (make EXTRA=-DMI_STREAM_STAMPS): lane 0 of every wave leaves s_memtime stamps of its phases in the
 // workspace behind the partial rows (16 per wave, 32-bit); see scripts/stream_stamps.py
 #ifdef MI_STREAM_STAMPS
+// -DMI_STAMP_REALTIME: the 100 MHz counter all XCDs share (absolute timelines) instead of the per-CU cycle counter
+#ifdef MI_STAMP_REALTIME
+#define MI_STAMP_NOW() ((unsigned)__builtin_amdgcn_s_memrealtime())
+#else
+#define MI_STAMP_NOW() ((unsigned)__builtin_readcyclecounter())
+#endif
 #define MI_SSTAMP(i)                                                                                          \
   do {                                                                                                        \
     if (lane == 0 && wave_ok && p.partials)                                                                   \
-      reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride)[g * 16 + (i)] =             \
-          (unsigned)__builtin_readcyclecounter();                                                             \
+      reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride)[g * 16 + (i)] = MI_STAMP_NOW();  \
   } while (0)
 #else
 #define MI_SSTAMP(i) do {} while (0)
+#define MI_STAMP_NOW() 0u
 #endif
 
 template <class E, int PR, int PC, int EPI>
@@ -731,7 +776,8 @@ static inline void geometry(int H, int W, SArgs& a) {
 // what the stream kernels handle: 12-bit packed sources in the standard layout with 4-byte aligned rows, whole
 // 8-pixel units, unit scale, frames below 1 GiB (the rest stays with tile::tile_kernel)
 static inline bool supported(const Params& p, int work_dtype) {
-  return p.src_kind == tile::SRC_PACKED12 && p.src_fast && p.W % 8 == 0 && p.H % 2 == 0 && p.in_scale == 1.f &&
+  // H >= 4: the border rows then only have the masks BORDER_DY tabulates
+  return p.src_kind == tile::SRC_PACKED12 && p.src_fast && p.W % 8 == 0 && p.H % 2 == 0 && p.H >= 4 && p.in_scale == 1.f &&
          (work_dtype == MI_F16 || work_dtype == MI_F32) && (int64_t)p.H * p.W * 3 / 2 < (int64_t)0x40000000;
 }
 

@@ -340,9 +340,10 @@ def test_reinhard_matches_the_published_photoreceptor_model(a, c, fp):
 
 
 def test_border_division_by_reciprocal():
-    """csrc/isp_stream.h div16_by<T>: q = a RN(1/T), e = fma(-q, T, a), q' = fma(e, RN(1/T), q) equals the IEEE
-    quotient a / T for the weight sums T that occur at the left / right image edge (11, 14, 15, 18, 19).
-    oracle/check_recip_div.c checks EVERY finite float (2^32 patterns; MI_ISP_EXHAUSTIVE=1, ~2 min); the default run
+    """csrc/isp_stream.h div16_by<T> / div16_by_rt: q = a RN(1/T), e = fma(-q, T, a), q' = fma(e, RN(1/T), q) equals
+    the IEEE quotient a / T for every weight sum T that occurs at an image edge or corner (10..22; 16 is exact by
+    construction).  oracle/check_recip_div.c checks EVERY finite float (2^32 patterns per T; MI_ISP_EXHAUSTIVE=1,
+    ~2.5 min on 8 cores: all twelve came out clean on 2026-10-04); the default run
     takes every 97th bit pattern.  The only exceptions are numerators whose quotient is subnormal (|a| < 2^-120) and -0,
     which an accumulated pixel value cannot be (zero or at least 2^-29 in magnitude; at least one positive weight)."""
     import subprocess, tempfile
@@ -352,4 +353,4 @@ def test_border_division_by_reciprocal():
         subprocess.run(["gcc", "-O2", "-march=x86-64-v3", "-fopenmp", "-ffp-contract=off", src, "-o", exe, "-lm"], check=True)
         stride = "1" if os.environ.get("MI_ISP_EXHAUSTIVE") else "97"
         out = subprocess.run([exe, stride], check=True, capture_output=True, text=True).stdout
-    assert "FAIL" not in out and out.count("ok") == 5, out
+    assert "FAIL" not in out and out.count("ok") == 12, out
