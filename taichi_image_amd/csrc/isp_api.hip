@@ -336,9 +336,11 @@ static int pipeline_frame_mega(tile::Params p, strm::SArgs a, int pattern, float
   m.s = a;
   m.fpw = reinterpret_cast<unsigned*>(ws);
   m.spin_limit = 100000;                                  // ~100 ms of polling before a wave gives up
+  m.l2_first = 1;
   m.poll_sleep = 0;                                       // extra 512-cycle naps between two polls (swept: 0 is best)
 #ifdef MI_ISP_MEASURE
   if (getenv("MI_ISP_POLL_SLEEP")) m.poll_sleep = (unsigned)atoi(getenv("MI_ISP_POLL_SLEEP"));
+  if (getenv("MI_ISP_L2_FIRST")) m.l2_first = (unsigned)atoi(getenv("MI_ISP_L2_FIRST"));
 #endif
   int dev = 0;
   MI_HIP(hipGetDevice(&dev));

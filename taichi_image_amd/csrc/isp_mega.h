@@ -66,6 +66,7 @@ struct MArgs {
   unsigned* fpw;                     // FrameParams as words (FP_EPOCH, FP_ERROR)
   unsigned spin_limit;               // polls before a wave gives up (error flag, garbage frame, no hang)
   unsigned poll_sleep;               // units of 512 cycles between two polls of the partial rows
+  unsigned l2_first;                 // the first round of a fold reads through the L2
 };
 
 // The block's contribution to a grid-wide reduction = its arrival at the barrier: every wave reduces in registers and
@@ -144,25 +145,47 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t ta
       have[u][c] = (int)role * 128 + u * 64 + lane >= a.n_blocks || (NV >= 7 && c == NCH - 1 && !rgb_sums);
     }
   unsigned spins = 0;
-  // Stage 0: watch ONE record - the last block's, which is dispatched last and (measured) posts last - with one lane
-  // until it is there.  2048 waves polling all records while others are still in their phase slow those down (their
-  // loads and posts queue behind the polls: the last blocks' phase A ran 4 us long); one request per wave and round
-  // does not.  Any other late block is waited for by stage 1.
-  for (;;) {
-    const uint32_t off = lane == 0 ? (uint32_t)(a.n_blocks - 1) * REC + 12u : INVALID_OFF;
-    const uint32_t t = __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, 16);
-    if (__builtin_amdgcn_readfirstlane(t) == tag) break;
-    for (unsigned z = 0; z <= m.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8);
-    if (++spins > m.spin_limit) break;                // stage 1 raises the error
+  // Stage 0: watch TWO typical records (lanes 0 and 1: the last block of the first half of the grid and the third last
+  // block) until both are there - by then nine blocks in ten have posted.  2048 waves polling all records while most
+  // blocks are still in their phase slow those down (their loads and posts queue behind the polls: the last blocks'
+  // phase A ran 4 us long); two requests per wave and round do not.  Four polls in flight, a new one every 512 cycles.
+  // The blocks dispatched last (measured: the last two post 2 - 3 us after the rest) are deliberately NOT watched:
+  // stage 1 asks for whatever is still missing every round, so their records are seen one round trip after they land.
+  {
+    const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
+    const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + 12u : INVALID_OFF;
+    const bool idle = !(lane < 2 && watch >= 0);
+    auto ask = [&]() { return __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, 16); };
+    auto nap = [&]() { for (unsigned z = 0; z <= m.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8); };
+    auto there = [&](uint32_t q) { return __builtin_amdgcn_ballot_w64(!idle && q != tag) == 0; };
+    uint32_t q0 = ask(); nap();
+    uint32_t q1 = ask(); nap();
+    uint32_t q2 = ask(); nap();
+    uint32_t q3 = ask();
+    for (;;) {
+      if (there(q0)) break;
+      nap(); q0 = ask();
+      if (there(q1)) break;
+      nap(); q1 = ask();
+      if (there(q2)) break;
+      nap(); q2 = ask();
+      if (there(q3)) break;
+      nap(); q3 = ask();
+      if ((spins += 4) > m.spin_limit) break;         // stage 1 raises the error
+    }
   }
-  // Stage 1: all records of this role
-  for (;;) {
+  // Stage 1: all records of this role.  The first round is served by the XCD's L2 (sc0: only the CU's own cache is
+  // bypassed): by now almost every record has been in memory for a while, the first wave of an XCD to ask brings a line
+  // in and the other 255 waves hit it - 2048 waves asking memory for 256 chunks each took 1.6 us.  A line the L2 holds
+  // from before its record was posted shows the old tag; such chunks, and every later round, bypass the L2 (sc1).
+  auto round = [&](auto auxc) {
+    constexpr int AUX = decltype(auxc)::value;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)((int)role * 128 + u * 64 + lane) * REC + 16u * c;
-        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, 16);
+        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, AUX);
         v[u][c] = have[u][c] ? v[u][c] : t;
       }
     bool all = true;
@@ -170,7 +193,11 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t ta
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) { have[u][c] = have[u][c] || v[u][c].w == tag; all = all && have[u][c]; }
-    const unsigned long long missing = __builtin_amdgcn_ballot_w64(!all);
+    return __builtin_amdgcn_ballot_w64(!all);
+  };
+  unsigned long long missing = m.l2_first ? round(std::integral_constant<int, 1>{}) : ~0ull;
+  while (missing != 0) {
+    missing = round(std::integral_constant<int, 16>{});
     if (missing == 0) break;
     // many records missing: the phase is still running elsewhere, poll rarely; few: the last arrivals, poll at once
     const unsigned naps = __builtin_popcountll(missing) > 16 ? 4u * m.poll_sleep + 1u : m.poll_sleep;
