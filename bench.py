@@ -186,6 +186,7 @@ def other_workloads(frames, host, device, frames_per_step):
     def run_batch(name, fr, alg_bytes, steps=150, **kw):
         bp = BatchPipeline(len(fr), H, W, device, use_graph=True, **kw)
         bp.prepare(fr)
+        time.sleep(0.3)          # a breather: several seconds of back-to-back load ended in a ~0.1 s clock dip on some boxes
         el = timed(lambda: bp(fr), steps, 10, device)
         us = el / (steps * len(fr)) * 1e6
         if os.environ.get("BENCH_DEBUG"):
@@ -197,24 +198,24 @@ def other_workloads(frames, host, device, frames_per_step):
                      "algorithmic_bytes_per_frame": alg_bytes, "frames_per_step": len(fr), "steps": steps}
         del bp
 
-    # config 2 with the u8 output of the ISP semantics (SURVEY 8(d): 4.5 B/px), through the headline chain
-    if whole_frame_fits(H, W, types.u8):
-        run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, dtype=types.u8, whole_frame=True)
-    else:
-        run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, dtype=types.u8, n_streams=2)
-    # config 2 on frames whose demosaiced bounds are NOT (0, 1): the statistics pass runs in full (no data-dependent
-    # shortcut); scene scaled into [0.1, 0.8]
     def rescale(p):
         b = p.reshape(H, -1, 3).astype(np.uint32)
         v = np.stack([b[..., 0] | ((b[..., 1] & 0xF) << 8), (b[..., 1] >> 4) | (b[..., 2] << 4)], -1).reshape(H, W)
         v = np.rint(v * 0.7 + 0.1 * 4095).astype(np.uint16)
         return pack12(v)
+    # frames whose demosaiced bounds are NOT (0, 1): the statistics pass / phase runs in full (no data-dependent
+    # shortcut); scene scaled into [0.1, 0.8]
     nonunit = [torch.from_numpy(rescale(host[i % len(host)])).to(device) for i in range(len(frames))]
-    run_batch("config2_multi_pass_chain_bounds_not_unit", nonunit, ALG_BYTES, n_streams=2)
-    # config 2 through the other chain (the headline is the whole-frame kernel when the frame fits it)
-    run_batch("config2_multi_pass_chain_2_streams", frames, ALG_BYTES, n_streams=2)
+    # config 2 with the u8 output of the ISP semantics (SURVEY 8(d): 4.5 B/px), through the headline chain
+    if whole_frame_fits(H, W, types.u8):
+        run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, dtype=types.u8, whole_frame=True)
+    else:
+        run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, dtype=types.u8, n_streams=2)
     if whole_frame_fits(H, W, types.f16):
         run_batch("config2_whole_frame_kernel_bounds_not_unit", nonunit, ALG_BYTES, whole_frame=True)
+    # config 2 through the other chain (the headline is the whole-frame kernel when the frame fits it)
+    run_batch("config2_multi_pass_chain_2_streams", frames, ALG_BYTES, n_streams=2)
+    run_batch("config2_multi_pass_chain_bounds_not_unit", nonunit, ALG_BYTES, n_streams=2)
     # config 3: Camera16(resize_width=1920): load_packed12 x frames + tonemap_reinhard(gamma=0.6) -> u8 1920x1440
     step = isp_step_fn(frames[:6], device)
     steps = 100

@@ -41,8 +41,8 @@ print("wave lifetime", rel[:, 8].mean(), np.percentile(rel[:, 8], [10, 50, 90]))
 for name, b0, ref in (("barrier 0", 9, 2), ("barrier 2", 12, 6)):
     f = s[:, b0] != 0
     if f.any():
-        d = (s[f][:, [b0, b0 + 1, b0 + 2]] - s[f][:, [ref]]) & 0xFFFFFFFF
-        print(name, "folders:", int(f.sum()), " poll matched / partials loaded / published after arrival: mean",
+        d = (s[f][:, [b0, b0 + 1]] - s[f][:, [ref]]) & 0xFFFFFFFF
+        print(name, "role-0 waves:", int(f.sum()), " poll matched / partial fold left in LDS, ticks after the wave's own arrival: mean",
               d.mean(axis=0).astype(int), "p90", np.percentile(d, 90, axis=0).astype(int))
 
 # absolute timeline: needs the stamps library built with -DMI_STAMP_REALTIME (100 MHz counter shared by the chip);
@@ -56,9 +56,9 @@ if os.environ.get("STAMP_RT"):
         print(f"{names[i] if i else 'entry':24s} {a.min():7.2f} {np.percentile(a,10):6.2f} {np.percentile(a,50):6.2f} {np.percentile(a,90):6.2f} {a.max():6.2f}")
     for name, b0 in (("barrier 0", 9), ("barrier 2", 12)):
         f = s[:, b0] != 0
-        d = (s[f][:, [b0, b0 + 1, b0 + 2]] - t0) / 100.0
-        print(name, "folding waves: poll matched min/p50/max", np.round(np.percentile(d[:, 0], [0, 50, 100]), 2),
-              " partials loaded", np.round(np.percentile(d[:, 1], [0, 50, 100]), 2), " published", np.round(np.percentile(d[:, 2], [0, 50, 100]), 2))
+        d = (s[f][:, [b0, b0 + 1]] - t0) / 100.0
+        print(name, "role-0 waves: poll matched min/p50/max", np.round(np.percentile(d[:, 0], [0, 50, 100]), 2),
+              " partial fold left in LDS", np.round(np.percentile(d[:, 1], [0, 50, 100]), 2))
     order = np.argsort(ab[:, 2])
     print("last arrivals at barrier 0 (wave, block, entry, A done, signalled):", [(int(w), int(w // 4), round(ab[w, 0], 2), round(ab[w, 1], 2), round(ab[w, 2], 2)) for w in order[-6:]])
     order = np.argsort(ab[:, 6])
