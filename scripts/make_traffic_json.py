@@ -6,7 +6,7 @@ d = f"gpurun_out/profile_{tag}"
 # kernel name fragments: stream_kernel<half, 0, 0, EPI> of the multi-pass chain, frame_kernel<0, 0> = whole-frame kernel
 KERNELS = [("pass0", "stream_kernelIDF16_Li0ELi0ELi1E"), ("pass1", "stream_kernelIDF16_Li0ELi0ELi2E"),
            ("pass2", "stream_kernelIDF16_Li0ELi0ELi3E"), ("pass3", "stream_kernelIDF16_Li0ELi0ELi4E"),
-           ("whole_frame", "mega::frame_kernel<0, 0>|frame_kernelILi0ELi0E")]   # rocprofv3 demangles some names
+           ("whole_frame", "mega::frame_kernel<0, 0, false>|frame_kernelILi0ELi0ELb0E")]   # rocprofv3 demangles some names
 FETCH_FACTOR = 2   # scratch/fetch_calib.hip: FETCH_SIZE reports half the bytes for 4-, 12- and 16-byte-per-lane streams
 def mean(sub, counter, kern):
     vals = []

@@ -74,11 +74,14 @@ struct MArgs {
 // {3 values, tag} write-through.  No wait, no counter, no workgroup barrier.
 template <int NV>
 MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (*red)[16], unsigned* arrived,
-                              float* area, int stride, int block, int wave, int lane, uint32_t tag) {
+                              float* area, int stride, int block, int wave, int lane, uint32_t tag, int n_live = NV) {
   constexpr int NCH = (NV + 2) / 3;
   float r[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) r[k] = op[k] == 0 ? wave_min(v[k]) : (op[k] == 1 ? wave_max(v[k]) : wave_sum(v[k]));
+  for (int k = 0; k < NV; ++k) {                      // values from n_live on are known to be zero (wave-uniform): not reduced
+    if (k < n_live) r[k] = op[k] == 0 ? wave_min(v[k]) : (op[k] == 1 ? wave_max(v[k]) : wave_sum(v[k]));
+    else r[k] = 0.f;
+  }
   unsigned before = 0;
   if (lane == 0) {
 #pragma unroll
@@ -299,7 +302,12 @@ MI_DEV void unpack_row(const uint32_t (&pk)[12], float (&t)[24]) {
   }
 }
 
-template <int PR, int PC>
+// RGB: color_adapt != 0 (per-channel sums in the statistics).  Two kernels instead of a run-time flag: with both kinds of
+// statistics in one body the register allocator spilled 13 VGPRs to scratch in phase A and reloaded them in B / C / D,
+// which cost 3.3 us per frame (58.2 -> 54.9).  Split, every variant fits 252 - 256 VGPRs without scratch - as long as the
+// Reinhard dispatch below stays a run-time branch on `ca0` (made compile-time, the RGB = false kernel spilled 17):
+// tests/test_abi.py::test_whole_frame_kernel_uses_no_scratch compiles the kernel and checks.
+template <int PR, int PC, bool RGB>
 __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   typedef half_t E;
   const SArgs& a = m.s;
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   }
   const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
   const bool any_left = __builtin_amdgcn_ballot_w64(is_left) != 0, any_right = __builtin_amdgcn_ballot_w64(is_right) != 0;
-  const bool want_rgb = p.ca != 0.f;
+  constexpr bool want_rgb = RGB;                        // the host picks the kernel by p.ca != 0
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
   Stats2 st; st.init();
 
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
     if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }
     const float v9[9] = {vmin, vmax, st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[9] = {0, 1, 0, 1, 2, 2, 2, 2, 2};
-    block_reduce_post<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane, tag);
+    block_reduce_post<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane, tag, want_rgb ? 9 : 6);
   }
 
   // the resident row RR as 24 fp32 values
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   }
   MI_SSTAMP(4);
   ReinhardK rk;
-  const bool ca0 = p.ca == 0.f;
+  const bool ca0 = p.ca == 0.f;                        // runtime on purpose: see the note on register allocation at the kernel's head
   rk.la = vgpr(p.la); rk.ca = vgpr(p.ca);
   rk.map_key = vgpr(sh_fp[FP_MAPKEY]); rk.ei = vgpr(sh_fp[FP_EI]);
   rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
