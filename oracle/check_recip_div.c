@@ -1,5 +1,5 @@
 /* TEST INFRASTRUCTURE: exhaustive check of the reciprocal division the streaming kernels use for the border
- * renormalisation at the image edges (csrc/isp_stream.h, div16_by<T> and div16_by_rt):
+ * renormalisation at the image edges (csrc/isp_stream.h, div16_by<T>):
  *     q = a * RN(1/T);  e = fma(-q, T, a);  q' = fma(e, RN(1/T), q)   ==   a / T   (IEEE, round to nearest even)
  * for every finite float a with |a| >= 2^-120 (so that the quotient is a normal number) or a == +0, T in {10..22} \ {16} (every in-bounds weight sum of
  * bayer.py:143-149 that occurs at a row or column border or in a corner: tile::make_border_table).   usage: check_recip_div [stride]   (stride 1 = all 2^32 bit patterns) */

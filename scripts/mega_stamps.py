@@ -73,20 +73,20 @@ if os.environ.get("STAMP_RT"):
     print("phase C duration per block: p50/p90/max", np.round(np.percentile(durc.max(axis=1), [50, 90, 100]), 2), " slowest:", [(int(b), round(float(durc[b].max()), 2)) for b in np.argsort(durc.max(axis=1))[-6:]])
     sig = (ab[:, 2] - ab[:, 1])
     print("reduce+post after phase A: p50/p90/p99/max", np.round(np.percentile(sig, [50, 90, 99, 100]), 2), " slowest waves:", [(int(w), int(w // 4), round(float(sig[w]), 2)) for w in np.argsort(sig)[-6:]])
-    hw = s[:, 15].astype(np.int64); xcc = (np.arange(2048) // 4) % 8     # XCC_ID (slot 14, overwritten by a barrier stamp in one wave per block) = block % 8
-    cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3
-    place = (xcc * 64 + se * 16 + sh * 8) * 0 + (xcc << 12 | se << 8 | sh << 4 | cu)     # a CU's id
-    pb = place.reshape(512, 4)
-    print("waves of a block on one CU:", bool((pb == pb[:, :1]).all()), " distinct CUs:", len(set(pb[:, 0].tolist())))
-    from collections import Counter
-    cnt = Counter(pb[:, 0].tolist())
-    print("blocks per CU histogram:", Counter(cnt.values()))
-    for b in (0, 1, 254, 255, 256, 257, 510, 511):
-        mates = [int(x) for x in np.nonzero(pb[:, 0] == pb[b, 0])[0]]
-        print(f"block {b}: xcc {int(xcc[4*b])} se {int(se[4*b])} sh {int(sh[4*b])} cu {int(cu[4*b])} simds {simd[4*b:4*b+4].tolist()}  blocks on this CU: {mates}  phase A {dur[b].max():.2f} us")
-    # phase A duration by XCC
-    for x in range(8):
-        m = xcc.reshape(512, 4)[:, 0] == x
-        print(f"xcc {x}: {int(m.sum())} blocks, phase A p50 {np.percentile(dur.max(axis=1)[m], 50):.2f} max {dur.max(axis=1)[m].max():.2f}")
-    for b in (0, 1, 255, 256, 510, 511):
-        print(f"raw HW_ID / XCC_ID of block {b}:", [f"{int(hw[4*b+w]):08x}/{int(s[4*b+w, 14]):08x}" for w in range(4)])
+    if os.environ.get("STAMP_HWID"):          # stamps build with -DMI_STAMP_HWID: slots 14 / 15 hold XCC_ID / HW_ID
+        hw = s[:, 15].astype(np.int64); xcc = (np.arange(2048) // 4) % 8
+        cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3
+        place = (xcc << 12 | se << 8 | sh << 4 | cu)
+        pb = place.reshape(512, 4)
+        from collections import Counter
+        print("waves of a block on one CU:", bool((pb == pb[:, :1]).all()), " distinct CUs:", len(set(pb[:, 0].tolist())), " blocks per CU:", Counter(Counter(pb[:, 0].tolist()).values()))
+        for b in (0, 1, 254, 255, 256, 257, 510, 511):
+            mates = [int(x) for x in np.nonzero(pb[:, 0] == pb[b, 0])[0]]
+            print(f"block {b}: xcc {int(xcc[4*b])} se {int(se[4*b])} sh {int(sh[4*b])} cu {int(cu[4*b])} simds {simd[4*b:4*b+4].tolist()}  blocks on this CU: {mates}  phase A {dur[b].max():.2f} us")
+    else:                                     # slots 15 / 14: prologue done, half of phase A's rows done
+        pro = ((s[:, 15] - s[:, 0]) / 100.0).reshape(512, 4); half = ((s[:, 14] - s[:, 15]) / 100.0).reshape(512, 4)
+        rest = ((s[:, 1] - s[:, 14]) / 100.0).reshape(512, 4)
+        med = lambda x: np.median(x, axis=1)
+        print("phase A split, median over blocks of the per-block median wave [us]: prologue", round(float(np.median(med(pro))), 2), " rows 0-5", round(float(np.median(med(half))), 2), " rows 6-11", round(float(np.median(med(rest))), 2))
+        for b in (0, 1, 2, 255, 256, 257, 258, 509, 510, 511):
+            print(f"  block {b}: prologue {med(pro)[b]:.2f}  rows 0-5 {med(half)[b]:.2f}  rows 6-11 {med(rest)[b]:.2f}")

@@ -350,12 +350,12 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   const uint32_t epoch = __builtin_amdgcn_readfirstlane(m.fpw[FP_EPOCH]);
   const uint32_t tag = epoch + 1u == 0u ? 1u : epoch + 1u;     // never 0: a zero-filled workspace matches no launch
   MI_SSTAMP(0);
-#ifdef MI_STREAM_STAMPS                                  // where the wave runs: HW_ID (SE / CU / SIMD / slot) and XCC_ID
-  if (lane == 0 && wave_ok && p.partials) {
-    unsigned* st_ = reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16;
-    st_[15] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
-    st_[14] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
-  }
+#ifdef MI_STREAM_STAMPS
+  unsigned* st_ = nullptr;
+  if (p.partials) st_ = reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16;
+#ifdef MI_STAMP_HWID                                     // where the wave runs: HW_ID (SE / CU / SIMD / slot) and XCC_ID
+  if (lane == 0 && wave_ok && st_) { st_[15] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); st_[14] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); }
+#endif
 #endif
   // ================================ phase A: demosaic once ================================
   float wq[8];
@@ -378,6 +378,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) decode_row(pro[q], lut, lane, win[q]);
   }
+#if defined(MI_STREAM_STAMPS) && !defined(MI_STAMP_HWID)
+  if (lane == 0 && wave_ok && st_) st_[15] = MI_STAMP_NOW();      // prologue done: table built, first four rows decoded
+#endif
   const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
   const bool any_left = __builtin_amdgcn_ballot_w64(is_left) != 0, any_right = __builtin_amdgcn_ballot_w64(is_right) != 0;
   constexpr bool want_rgb = RGB;                        // the host picks the kernel by p.ca != 0
@@ -393,6 +396,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
       load_row(r + 6, raw[IB % 2][0]);
       load_row(r + 7, raw[IB % 2][1]);
     }
+#if defined(MI_STREAM_STAMPS) && !defined(MI_STAMP_HWID)
+    if constexpr (IB == 3) { if (lane == 0 && wave_ok && st_) st_[14] = MI_STAMP_NOW(); }      // half of the rows done
+#endif
     if (r < r_end) {                                  // wave-uniform
       WinRow w6[6];
 #pragma unroll

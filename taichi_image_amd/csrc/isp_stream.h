@@ -377,7 +377,7 @@ MI_DEV void border_fix_cols(float (&v)[24], bool is_left, bool is_right, bool an
 
 // {T, RN(1/T)} per [kernel][row mask slot][column mask slot][channel], masks in the order {31, 28, 30, 15, 7} (inside,
 // offsets -2 -1 outside, -2 outside, +2 outside, +1 +2 outside): the only masks an image of at least 4 rows and
-// columns has.  A uniform slot index makes every access a scalar load, and no load depends on another.
+// columns has.  Compile-time only: the kernels take their divisors from it as template constants.
 struct DY { float d, y; };
 struct BorderDY { DY t[4][5][5][3]; };
 constexpr BorderDY make_border_dy() {
@@ -404,39 +404,38 @@ constexpr bool border_dy_in_range() {
   return true;
 }
 static_assert(border_dy_in_range(), "a weight sum outside the range oracle/check_recip_div.c checks");
-__constant__ const BorderDY BORDER_DY = make_border_dy();
+constexpr BorderDY BORDER_DY = make_border_dy();
 
-// div16_by<T> with the divisor in registers: d = T, y = RN(1/T) (same arithmetic, same exhaustive check)
-MI_DEV float div16_by_rt(float x, float d, float y) {
-  const float a = x * 16.f;
-  const float q = a * y;
-  const float e = __builtin_fmaf(-q, d, a);
-  return __builtin_fmaf(e, y, q);
-}
-
-// the image's first and last two rows (rmask != 31, wave-uniform): every pixel of the row is renormalised.  Divisor
-// and reciprocal come from BORDER_DY through scalar loads (uniform slot), one pair per lane kind, and the division is
-// the reciprocal sequence of div16_by: 24 IEEE divisions per row made the border bands the last to finish their
-// phase (+2.5 us on the whole-frame kernel's first barrier).
-template <int PR, int PC, int I>
-MI_DEV void border_fix_rows(float (&v)[24], int rmask, bool is_left, bool is_right) {
-  const int rs = __builtin_amdgcn_readfirstlane(rmask == 28 ? 1 : rmask == 30 ? 2 : rmask == 15 ? 3 : rmask == 7 ? 4 : 0);
-  // rs > 0 for every border row of an image with at least 4 rows (strm::supported refuses smaller ones)
+// the image's first and last two rows (rmask != 31, wave-uniform): every pixel of the row is renormalised with the
+// reciprocal sequence of div16_by<T>, all sums compile-time constants.  The row's parity I fixes which two rows it can
+// be (H is even and every wave starts on an even row: strm::supported, geometry): I = 0 -> row 0 (mask 28) or row
+// H - 2 (mask 15), I = 1 -> row 1 (30) or row H - 1 (7); one wave-uniform branch picks the copy.  History: 24 IEEE
+// divisions per row (+ 1.5 us on the band), then a {T, 1/T} table in constant memory behind scalar loads - the scalar
+// cache misses cost a memory round trip per border row (+ 1 - 1.6 us on the top and bottom bands of the whole-frame
+// kernel's phase A, which its first barrier waits for).
+template <int PR, int PC, int I, int RS>
+MI_DEV void border_fix_rows_ct(float (&v)[24], bool is_left, bool is_right) {
   static_for<0, 8>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     constexpr int KIDX = ((I + PR) & 1) + 2 * ((k + PC) & 1);
-    constexpr int cs = k == 0 ? 1 : k == 1 ? 2 : k == 6 ? 3 : k == 7 ? 4 : 0;     // this pixel's border slot, if any
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float d = BORDER_DY.t[KIDX][rs][0][ch].d, y = BORDER_DY.t[KIDX][rs][0][ch].y;
-      if constexpr (cs != 0) {
-        const bool mine = cs <= 2 ? is_left : is_right;
-        d = mine ? BORDER_DY.t[KIDX][rs][cs][ch].d : d;
-        y = mine ? BORDER_DY.t[KIDX][rs][cs][ch].y : y;
+    constexpr int cs = k == 0 ? 1 : k == 1 ? 2 : k == 6 ? 3 : k == 7 ? 4 : 0;     // this pixel's column-border slot, if any
+    static_for<0, 3>([&](auto cc) {
+      constexpr int ch = decltype(cc)::value;
+      constexpr int Tm = (int)BORDER_DY.t[KIDX][RS][0][ch].d, Te = (int)BORDER_DY.t[KIDX][RS][cs][ch].d;
+      const float x = v[3 * k + ch];
+      float q = div16_by<Tm>(x);
+      if constexpr (cs != 0 && Te != Tm) {
+        const float qe = div16_by<Te>(x);
+        q = (cs <= 2 ? is_left : is_right) ? qe : q;
       }
-      v[3 * k + ch] = div16_by_rt(v[3 * k + ch], d, y);
-    }
+      v[3 * k + ch] = q;
+    });
   });
+}
+template <int PR, int PC, int I>
+MI_DEV void border_fix_rows(float (&v)[24], int rmask, bool is_left, bool is_right) {
+  if (rmask == (I == 0 ? 28 : 30)) border_fix_rows_ct<PR, PC, I, I == 0 ? 1 : 2>(v, is_left, is_right);     // wave-uniform
+  else border_fix_rows_ct<PR, PC, I, I == 0 ? 3 : 4>(v, is_left, is_right);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -340,7 +340,7 @@ def test_reinhard_matches_the_published_photoreceptor_model(a, c, fp):
 
 
 def test_border_division_by_reciprocal():
-    """csrc/isp_stream.h div16_by<T> / div16_by_rt: q = a RN(1/T), e = fma(-q, T, a), q' = fma(e, RN(1/T), q) equals
+    """csrc/isp_stream.h div16_by<T>: q = a RN(1/T), e = fma(-q, T, a), q' = fma(e, RN(1/T), q) equals
     the IEEE quotient a / T for every weight sum T that occurs at an image edge or corner (10..22; 16 is exact by
     construction).  oracle/check_recip_div.c checks EVERY finite float (2^32 patterns per T; MI_ISP_EXHAUSTIVE=1,
     ~2.5 min on 8 cores: all twelve came out clean on 2026-10-04); the default run
