@@ -212,6 +212,28 @@ def test_whole_frame_kernel_streams_are_serialised(ti, dev, scenes):
         assert_close(outs[k].cpu().numpy(), refs[k], f"stream {k}")
 
 
+def test_whole_frame_kernel_shares_its_workspace(ti, dev, rng, scenes):
+    """One workspace (same stream, same byte size) serves frames of different geometry, both chains and both kinds of
+    bounds in any order: the barrier records carry the workspace's launch count, so records a smaller grid or the other
+    chain left behind never count, and nothing has to be reset between launches."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    from taichi_image_amd import _native
+    cases = {"4k": packed_from(scenes[0]), "4k-inside": packed_from(scenes[1], 0.7, 0.1),
+             "small": natural_packed12(rng, 64, 512), "odd": natural_packed12(rng, 130, 1544)}
+    refs = {k: c_oracle.pipeline12_reinhard(v, work="f16", out="f16") for k, v in cases.items()}
+    frames = {k: torch.from_numpy(v).to(dev) for k, v in cases.items()}
+    ws = {k: _native.workspace(v.shape[0], v.shape[1] * 2 // 3, dev).data_ptr() for k, v in cases.items()}
+    assert len(set(ws.values())) == 1, "the cases are meant to share one workspace"
+    order = [("4k", True), ("small", True), ("4k-inside", True), ("small", False), ("odd", True), ("4k", False),
+             ("4k", True), ("4k-inside", True), ("odd", True), ("4k", True)]
+    for step, (name, whole) in enumerate(order):
+        got = pipeline12_reinhard(frames[name], whole_frame=whole)
+        torch.cuda.synchronize()
+        H, Wp = cases[name].shape
+        assert _error_word(ti, H, Wp * 2 // 3, dev) == 0, f"step {step}: a grid barrier timed out"
+        assert_close(got.cpu().numpy(), refs[name], f"step {step}: {name}, whole_frame={whole}")
+
+
 def test_whole_frame_kernel_refuses_what_it_cannot_hold(ti, dev):
     from taichi_image_amd.pipeline import pipeline12_reinhard, whole_frame_fits
     assert not whole_frame_fits(3072 + 12, 4096)            # one row band more than the chip holds
