@@ -231,7 +231,7 @@ def other_workloads(frames, host, device, frames_per_step):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000, help="steps of the timed region (8 frames each: ~0.6 s)")
+    ap.add_argument("--steps", type=int, default=1200, help="steps of the timed region (8 frames each: ~0.54 s)")
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--frames", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per rank (frames in flight)")
