@@ -234,6 +234,22 @@ def test_whole_frame_kernel_shares_its_workspace(ti, dev, rng, scenes):
         assert_close(got.cpu().numpy(), refs[name], f"step {step}: {name}, whole_frame={whole}")
 
 
+def test_whole_frame_kernel_is_deterministic(ti, dev, scenes):
+    """The barrier folds have a fixed order: every launch of a frame gives the same bits (scripts/wf_soak.py runs this for
+    two million frames); a stale or torn barrier record would show up here as a differing output or an error word."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    frames = [torch.from_numpy(packed_from(scenes[0])).to(dev), torch.from_numpy(packed_from(scenes[1], 0.7, 0.1)).to(dev)]
+    first = [pipeline12_reinhard(f, whole_frame=True).clone() for f in frames]
+    outs = [torch.empty_like(o) for o in first]
+    for it in range(400):
+        k = it % 3 == 0
+        pipeline12_reinhard(frames[k], out=outs[k], whole_frame=True)
+        if it % 100 == 99:
+            torch.cuda.synchronize()
+            assert _error_word(ti, 3072, 4096, dev) == 0
+            assert torch.equal(outs[0], first[0]) and torch.equal(outs[1], first[1]), f"launch {it}: output changed"
+
+
 def test_whole_frame_kernel_refuses_what_it_cannot_hold(ti, dev):
     from taichi_image_amd.pipeline import pipeline12_reinhard, whole_frame_fits
     assert not whole_frame_fits(3072 + 12, 4096)            # one row band more than the chip holds
