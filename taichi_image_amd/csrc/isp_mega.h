@@ -150,10 +150,10 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t ta
   unsigned spins = 0;
   // Stage 0: watch TWO typical records (lanes 0 and 1: the last block of the first half of the grid and the third last
   // block) until both are there - by then nine blocks in ten have posted.  2048 waves polling all records while most
-  // blocks are still in their phase slow those down (their loads and posts queue behind the polls: the last blocks'
-  // phase A ran 4 us long); two requests per wave and round do not.  Four polls in flight, a new one every 512 cycles.
-  // The blocks dispatched last (measured: the last two post 2 - 3 us after the rest) are deliberately NOT watched:
-  // stage 1 asks for whatever is still missing every round, so their records are seen one round trip after they land.
+  // blocks are still in their phase slow those down (their loads and posts queue behind the polls: posts took up to
+  // 4.6 us instead of 1); two requests per wave and round do not.  Four polls in flight, a new one every 512 cycles.
+  // Whichever blocks post last are deliberately NOT waited for here: stage 1 asks for whatever is still missing every
+  // round, so a straggler's record is seen one round trip after it lands.
   {
     const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
     const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + 12u : INVALID_OFF;
