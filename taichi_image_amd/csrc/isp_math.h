@@ -78,9 +78,12 @@ MI_DEV float linear_px(float x, float lo, float inv, float gamma_inv, float scal
 // The same for N values with ONE scalar branch on gamma.  Written per value, hipcc if-converts the
 // branch into select(pow(v), v): a v_log + v_exp (quarter-rate) per value even when gamma == 1.
 // The empty volatile asm makes the pow block non-speculatable, so it stays a real branch.
+#ifndef MI_CENSUS_GAMMA            /* reading aid of scripts/isa_census.py: gamma == 1 as a constant */
+#define MI_CENSUS_GAMMA(expr) (expr)
+#endif
 template <int N>
 MI_DEV void linear_n(float (&v)[N], float lo, float inv, float gamma_inv, float scale) {
-  if (gamma_inv != 1.f) {
+  if (MI_CENSUS_GAMMA(gamma_inv != 1.f)) {
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = clamp01(hw_pow((v[i] - lo) * inv, gamma_inv)) * scale;

@@ -39,6 +39,19 @@ namespace mega {
 
 using namespace strm;
 
+// Reading aid (scripts/isa_census.py compiles isp_mega_p0.hip with -DMI_MEGA_CENSUS to assembly): the run-time choices
+// of the headline configuration become constants (interior band, no colour matrix, bounds (0, 1), color_adapt == 0, f16
+// output) so that each phase is one straight-line stretch between two "; MI_MARK n" comments.  Never part of the library.
+#ifdef MI_MEGA_CENSUS
+#define MI_CENSUS(expr, val) (val)
+#undef MI_SSTAMP
+#define MI_SSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MI_MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MI_CMARK(i) MI_SSTAMP(i)
+#else
+#define MI_CENSUS(expr, val) (expr)
+#define MI_CMARK(i) do {} while (0)
+#endif
+
 constexpr int ROWS = 12;             // rows per wave
 constexpr int NL = 5;                // of which live in LDS ...
 constexpr int NR = ROWS - NL;        // ... and in registers
@@ -378,6 +391,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) decode_row(pro[q], lut, lane, win[q]);
   }
+  MI_CMARK(10);
 #if defined(MI_STREAM_STAMPS) && !defined(MI_STAMP_HWID)
   if (lane == 0 && wave_ok && st_) st_[15] = MI_STAMP_NOW();      // prologue done: table built, first four rows decoded
 #endif
@@ -408,9 +422,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
         const int row = r + I;
         float v[24];
         accumulate_row<PR, PC, I, true>(w6, wq, v);
-        if (row < 2 || row >= p.H - 2) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
-        else if (any_left || any_right) border_fix_cols<PR, PC, I>(v, is_left, is_right, any_left, any_right);
-        if (p.has_ccm) {                              // bayer.py:152-153, sequential fp32 dot
+        if (MI_CENSUS(row < 2 || row >= p.H - 2, false)) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
+        else if (MI_CENSUS(any_left || any_right, false)) border_fix_cols<PR, PC, I>(v, is_left, is_right, any_left, any_right);
+        if (MI_CENSUS(p.has_ccm, false)) {            // bayer.py:152-153, sequential fp32 dot
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const float x = v[3 * k], y = v[3 * k + 1], z = v[3 * k + 2];
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
 #endif
   MI_SSTAMP(3);
   const float lo_s = sh_fp[FP_LO], inv_s = sh_fp[FP_INV];
-  const bool unit = lo_s == 0.f && inv_s == 1.f;
+  const bool unit = MI_CENSUS(lo_s == 0.f && inv_s == 1.f, true);
   // per-pixel operands live in VGPRs: a VALU instruction with an SGPR operand issues at half rate
   const float lo = vgpr(lo_s), inv = vgpr(inv_s);
   if (!unit) {
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   }
   MI_SSTAMP(4);
   ReinhardK rk;
-  const bool ca0 = p.ca == 0.f;                        // runtime on purpose: see the note on register allocation at the kernel's head
+  const bool ca0 = MI_CENSUS(p.ca == 0.f, true);        // runtime on purpose: see the note on register allocation at the kernel's head
   rk.la = vgpr(p.la); rk.ca = vgpr(p.ca);
   rk.map_key = vgpr(sh_fp[FP_MAPKEY]); rk.ei = vgpr(sh_fp[FP_EI]);
   rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
     // staging: the LDS slot of a row that has been consumed (its own, or row 0's for the register rows)
     uint4* stage = xl[wave][RR < NL ? RR : 0];
     const uint32_t row_base = (uint32_t)(r_begin + RR) * out_pitch + band_base;
-    switch (p.out_dtype) {
+    switch (MI_CENSUS(p.out_dtype, MI_F16)) {
       case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, q); break;
       case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, q); break;
       default: {                                        // f16: pairs leave through v_cvt_pk_f16_f32 (half the conversions)
