@@ -6,11 +6,17 @@
 
 A "step" is one pass of the hot path over one batch of synthetic frames: BASELINE config 2,
 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap -> f16 RGB (the stateless chain of the
-reference's test/pipeline.py:26-32), `--frames` frames per rank per step, one frame per HIP
-stream in flight, the step replayed as a HIP graph captured inside the library
-(mi_isp_pipeline12_graph_create).  Frames are independent, so N ranks shard the batch with no
-data-path collective ("scaling": "weak": per-GPU work is fixed).  Inputs are resident in HBM before
-the timed region; value = total megapixels (sensor pixels) of all ranks / max-over-ranks wall time.
+reference's test/pipeline.py:26-32), `--frames` frames per rank per step (default 64, BASELINE's
+batch).  Headline chain: the whole-frame kernel (csrc/isp_mega.h), ONE launch per step - the resident
+grid walks through the 64 frames.  (--chain multi-pass: the streaming chain, one frame per HIP stream
+in flight, the step replayed as a HIP graph captured inside the library.)  Frames are independent, so
+N ranks shard the batch with no data-path collective ("scaling": "weak": per-GPU work is fixed).
+Inputs are resident in HBM before the timed region; value = total megapixels (sensor pixels) of all
+ranks / max-over-ranks wall time.
+
+Started without a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) and N > 1, the process - before it
+touches a GPU - spawns N rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays
+rank 0's JSON line and exits with the worst return code.
 
 One JSON line is printed by rank 0; besides the driver's contract keys it carries
   roofline        : the dominant kernel (the pass that reads the packed frame and writes the output: final map +
@@ -177,25 +183,27 @@ def isp_workload(args, rank, world, device):
 
 
 def other_workloads(frames, host, device, frames_per_step):
-    """Short driver-visible runs of the other single-GPU configurations (rank 0, N=1)."""
+    """Short driver-visible runs of the other single-GPU configurations (rank 0, N=1).  Every entry: three timed runs,
+    the median reported and all three listed (no pauses between the runs: round 2 slept 0.3 s in front of each)."""
     from taichi_image_amd import types
     from taichi_image_amd.pipeline import BatchPipeline, whole_frame_fits
     from taichi_image_amd.synthetic import pack12
     res = {}
 
-    def run_batch(name, fr, alg_bytes, steps=150, **kw):
+    def entry(name, us_runs, alg_bytes, n_frames, steps, **more):
+        us = float(np.median(us_runs))
+        res[name] = {"MP_per_s": round(MP / us * 1e6, 1), "us_per_frame": round(us, 2),
+                     "us_per_frame_runs": [round(u, 2) for u in us_runs],
+                     "frac_of_hbm_roofline": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_frame": alg_bytes, "frames_per_step": n_frames, "steps": steps, **more}
+
+    def run_batch(name, fr, alg_bytes, steps, **kw):
         bp = BatchPipeline(len(fr), H, W, device, use_graph=True, **kw)
         bp.prepare(fr)
-        time.sleep(0.3)          # a breather: several seconds of back-to-back load ended in a ~0.1 s clock dip on some boxes (DESIGN 5.1d)
-        el = timed(lambda: bp(fr), steps, 10, device)
-        us = el / (steps * len(fr)) * 1e6
-        if os.environ.get("BENCH_DEBUG"):
-            more = [timed(lambda: bp(fr), steps, 10, device) / (steps * len(fr)) * 1e6 for _ in range(3)]
-            print(f"[debug] {name}: {us:.1f} {more} ws={bp.ws.data_ptr():#x} outs={[hex(o.data_ptr()) for o in bp.outputs]} "
-                  f"in={[hex(f.data_ptr()) for f in fr]}", file=sys.stderr, flush=True)
-        res[name] = {"MP_per_s": round(MP / us * 1e6, 1), "us_per_frame": round(us, 2),
-                     "frac_of_hbm_roofline": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                     "algorithmic_bytes_per_frame": alg_bytes, "frames_per_step": len(fr), "steps": steps}
+        runs = [timed(lambda: bp(fr), steps, 3, device) / (steps * len(fr)) * 1e6 for _ in range(3)]
+        lost = bp.check(fr)
+        entry(name, runs, alg_bytes, len(fr), steps, whole_frame_faults=len(lost),
+              chain="whole-frame kernel, one launch per step" if bp.whole_frame else "multi-pass chain")
         del bp
 
     def rescale(p):
@@ -203,45 +211,82 @@ def other_workloads(frames, host, device, frames_per_step):
         v = np.stack([b[..., 0] | ((b[..., 1] & 0xF) << 8), (b[..., 1] >> 4) | (b[..., 2] << 4)], -1).reshape(H, W)
         v = np.rint(v * 0.7 + 0.1 * 4095).astype(np.uint16)
         return pack12(v)
-    # frames whose demosaiced bounds are NOT (0, 1): the statistics pass / phase runs in full (no data-dependent
+    # frames whose demosaiced bounds are NOT (0, 1): the statistics phase / pass runs (no data-dependent
     # shortcut); scene scaled into [0.1, 0.8]
-    nonunit = [torch.from_numpy(rescale(host[i % len(host)])).to(device) for i in range(len(frames))]
+    nu_dev = [torch.from_numpy(rescale(host[i])).to(device) for i in range(len(host))]
+    nonunit = [nu_dev[i % len(nu_dev)] for i in range(len(frames))]
+    wf_steps = max(4, 1200 // max(1, len(frames)))         # ~60 ms per run at 64 frames per step
     # config 2 with the u8 output of the ISP semantics (4.5 B/px), through the headline chain
-    if whole_frame_fits(H, W, types.u8):
-        run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, dtype=types.u8, whole_frame=True)
-    else:
-        run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, dtype=types.u8, n_streams=2)
+    run_batch("config2_u8_out", frames, BYTES_IN + H * W * 3, wf_steps, dtype=types.u8)
     if whole_frame_fits(H, W, types.f16):
-        run_batch("config2_whole_frame_kernel_bounds_not_unit", nonunit, ALG_BYTES, whole_frame=True)
+        run_batch("config2_whole_frame_kernel_bounds_not_unit", nonunit, ALG_BYTES, wf_steps, whole_frame=True)
     # config 2 through the other chain (the headline is the whole-frame kernel when the frame fits it)
-    run_batch("config2_multi_pass_chain_2_streams", frames, ALG_BYTES, n_streams=2)
-    run_batch("config2_multi_pass_chain_bounds_not_unit", nonunit, ALG_BYTES, n_streams=2)
+    run_batch("config2_multi_pass_chain_2_streams", frames[:8], ALG_BYTES, 100, n_streams=2, whole_frame=False)
+    run_batch("config2_multi_pass_chain_bounds_not_unit", nonunit[:8], ALG_BYTES, 100, n_streams=2, whole_frame=False)
     # config 3: Camera16(resize_width=1920): load_packed12 x frames + tonemap_reinhard(gamma=0.6) -> u8 1920x1440
     step = isp_step_fn(frames[:6], device)
     steps = 100
-    el = timed(step, steps, 10, device)
-    us = el / (steps * 6) * 1e6
-    alg3 = BYTES_IN + 1440 * 1920 * 3
-    res["config3_camera16_resize1920"] = {"MP_per_s": round(MP / us * 1e6, 1), "us_per_frame": round(us, 2),
-                                          "frac_of_hbm_roofline": round(alg3 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                          "algorithmic_bytes_per_frame": alg3, "frames_per_step": 6, "steps": steps}
+    runs = [timed(step, steps, 5, device) / (steps * 6) * 1e6 for _ in range(3)]
+    entry("config3_camera16_resize1920", runs, BYTES_IN + 1440 * 1920 * 3, 6, steps)
+    # config 3b: the nominal 1920x1080 through the resize primitive's per-axis scale (interpolate.py:83)
+    # on the demosaiced 4K f16 image: load_packed12 at full size, resize_bilinear(scale=(0.3515625, 0.46875)) -> f16 / u8
+    import taichi_image_amd as ti
+    from taichi_image_amd import interpolate
+    isp_full = ti.Camera16(ti.BayerPattern.RGGB, device=device)
+    for odt, nbytes, tag in ((types.f16, 31315968, "f16"), (types.u8, 25095168, "u8")):
+        def step3b():
+            for f in frames[:4]:
+                interpolate.resize_bilinear(isp_full.load_packed12(f), scale=(0.3515625, 0.46875), dtype=odt)
+        runs = [timed(step3b, 50, 3, device) / (50 * 4) * 1e6 for _ in range(3)]
+        entry(f"config3b_resize_1920x1080_{tag}", runs, nbytes, 4, 50,
+              note="load_packed12 (full-size f16 RGB materialised, as the reference does) + resize_bilinear with the per-axis scale")
+    # the reference's own bench workload (bench/camera_isp.py:19-45): 6 cameras at full resolution, Camera16 + reinhard
+    isp6 = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, device=device)
+    def step6():
+        isp6.tonemap_reinhard([isp6.load_packed12(f) for f in frames[:6]], gamma=0.6)
+    runs = [timed(step6, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
+    entry("reference_bench_6_cameras_full_resolution", runs, BYTES_IN + H * W * 3, 6, 40)
     return res
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N rank processes of this script, before anything touches a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max((abs(rc) for rc in rcs), default=0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1200, help="steps of the timed region (8 frames each: ~0.54 s)")
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--frames", type=int, default=8, help="frames per rank per step")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="steps of the timed region (default: 160 for config 2 = 64 frames each, ~0.5 s; 200 for the ISP workloads)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5)")
+    ap.add_argument("--frames", type=int, default=None,
+                    help="frames per rank per step (default: 64 for config 2, BASELINE's batch; 8 for the ISP workloads)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per rank (frames in flight)")
     ap.add_argument("--profile-every", type=int, default=2,
                     help="HIP events around the passes of every n-th frame of the launch-by-launch steps")
     ap.add_argument("--no-graph", action="store_true",
                     help="issue every step launch by launch instead of replaying the captured HIP graph")
-    ap.add_argument("--eager-every", type=int, default=25,
+    ap.add_argument("--eager-every", type=int, default=None,
                     help="every n-th step of the timed region is issued launch by launch so that the per-pass "
-                         "events (--profile-every) can be recorded (events inside a graph cannot be timed)")
+                         "events (--profile-every) can be recorded (events inside a graph cannot be timed); default: "
+                         "1 for the whole-frame chain (one 3 ms launch per step: nothing to gain from a graph), 25 for "
+                         "the multi-pass chain")
     ap.add_argument("--chain", default="auto", choices=["auto", "whole-frame", "multi-pass"],
                     help="config 2 through the single-launch whole-frame kernel (csrc/isp_mega.h; frames one after the "
                          "other) or through the multi-pass streaming chain (frames on --streams streams); auto = the "
@@ -253,6 +298,16 @@ def main():
                          "tonemap_reinhard(gamma=0.6), config 3 | isp-shared-stats: the same with the rolling metering "
                          "statistics all-reduced over the ranks (config 5)")
     args = ap.parse_args()
+    isp = args.workload != "config2"
+    if args.steps is None:
+        args.steps = 200 if isp else 160
+    if args.warmup is None:
+        args.warmup = 5
+    if args.frames is None:
+        args.frames = 8 if isp else 64
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -275,9 +330,7 @@ def main():
     from taichi_image_amd import synthetic
     from taichi_image_amd.pipeline import BatchPipeline
 
-    if args.workload != "config2":
-        if args.steps == 1000:
-            args.steps = 200
+    if isp:
         return isp_workload(args, rank, world, device)
 
     # distinct synthetic frames per rank (seeds 1234 + k); 4 distinct, cycled
@@ -287,7 +340,14 @@ def main():
     use_graph = not args.no_graph
     from taichi_image_amd import types as _types
     from taichi_image_amd.pipeline import whole_frame_fits
-    whole = args.chain == "whole-frame" or (args.chain == "auto" and whole_frame_fits(H, W, _types.f16))
+    # ranks that share a device (the gloo rehearsal on a box with fewer GPUs than ranks) cannot use the whole-frame
+    # kernel: it needs the chip to itself and only orders launches inside ONE process
+    shared_device = world > 1 and backend == "gloo" and world > torch.cuda.device_count()
+    whole = args.chain == "whole-frame" or (args.chain == "auto" and whole_frame_fits(H, W, _types.f16) and not shared_device)
+    if args.eager_every is None:
+        args.eager_every = 1 if whole else 25
+    if whole:
+        args.profile_every = 1                     # every launch of the timed region carries its events
     bp = BatchPipeline(args.frames, H, W, device, n_streams=args.streams, use_graph=use_graph, whole_frame=whole)
 
     def barrier():
@@ -303,7 +363,7 @@ def main():
     barrier()
     # events around every data pass of the launch-by-launch steps inside the timed region (rank 0's line)
     n_eager = (args.steps + args.eager_every - 1) // max(1, args.eager_every) if use_graph else args.steps
-    _native.check(_native.lib().mi_isp_profile_enable(args.frames * n_eager, args.profile_every))
+    _native.check(_native.lib().mi_isp_profile_enable((1 if whole else args.frames) * n_eager, args.profile_every))
     t0 = time.perf_counter()
     for step in range(args.steps):
         bp(frames, eager=(not use_graph) or (step % max(1, args.eager_every) == 0))
@@ -312,6 +372,7 @@ def main():
     live_us, live_n = (ctypes.c_float * 4)(), ctypes.c_int(0)
     _native.check(_native.lib().mi_isp_profile_collect(live_us, ctypes.byref(live_n)))
     _native.check(_native.lib().mi_isp_profile_enable(0, 1))
+    faults = len(bp.check(frames)) if whole else 0          # after the timed region: every output valid, or repaired and counted
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -323,13 +384,13 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         live = [float(v) for v in live_us]            # in-situ averages over the timed region
         if whole:
-            # one kernel per frame: it IS the dominant kernel (reads the packed frame, writes the output)
+            # one kernel per step: it IS the dominant kernel (reads the packed frames, writes the outputs)
             from taichi_image_amd.pipeline import pipeline12_reinhard
-            iso = timed(lambda: pipeline12_reinhard(frames[0], out=bp.outputs[0], whole_frame=True), 100, 10, device) / 100 * 1e6
+            iso = timed(lambda: pipeline12_reinhard(frames[0], out=bp.outputs[0], whole_frame=True, check=False), 100, 10, device) / 100 * 1e6
             passes = [iso, 0.0, 0.0, 0.0]
-            names = ["mega::frame_kernel<RGGB> (whole chain: unpack + demosaic + statistics + Reinhard + final map, "
-                     "grid barriers inside)", "-", "-", "-"]
-            dom, dom_bytes = 0, ALG_BYTES
+            names = [f"mega::frame_kernel<RGGB> (whole chain of {args.frames} frames in one launch: unpack + demosaic + statistics + "
+                     "Reinhard + final map, grid barriers inside)", "-", "-", "-"]
+            dom, dom_bytes = 0, ALG_BYTES * args.frames
         else:
             passes = time_passes(frames[0], bp.outputs[0], bp.ws.data_ptr(), device)
             names = PASS_NAMES
@@ -357,10 +418,12 @@ def main():
             "config": {"workload": "config 2: 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap (stateless, "
                                    "gamma 1) -> f16 RGB", "frames_per_rank_per_step": args.frames,
                        "streams_per_rank": 1 if whole else args.streams, "work_dtype": "f16",
-                       "chain": ("whole-frame kernel: one persistent launch per frame (csrc/isp_mega.h), frames one after the "
-                                 "other" if whole else "multi-pass streaming chain (csrc/isp_stream.h), one frame per stream in flight"),
-                       "launch": (f"HIP graph replay of the step (captured inside the library); every {args.eager_every}th "
-                                  "step launch by launch for the per-pass events" if use_graph else "launch by launch"),
+                       "chain": ("whole-frame kernel: one persistent launch per step (csrc/isp_mega.h), the resident grid walks "
+                                 "through the step's frames" if whole else
+                                 "multi-pass streaming chain (csrc/isp_stream.h), one frame per stream in flight"),
+                       "launch": ("launch by launch, HIP events around every launch" if (whole or not use_graph) else
+                                  f"HIP graph replay of the step (captured inside the library); every {args.eager_every}th "
+                                  "step launch by launch for the per-pass events"),
                        "sharding": f"frames x{world}, no collective"},
             "us_per_frame": round(elapsed / (args.frames * args.steps) * 1e6, 2),
             "timed_region_s": round(elapsed, 3),
@@ -370,10 +433,14 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": round(dom_us, 2),
-                         "launches_timed": int(live_n.value), "isolated_launch_us": round(passes[dom], 2),
-                         "isolated_frac": round(dom_bytes / (passes[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "launches_timed": int(live_n.value),
+                         "frames_per_launch": args.frames if whole else 1,
+                         "avg_us_per_frame": round(dom_us / (args.frames if whole else 1), 2),
+                         "single_frame_launch_us": round(passes[dom], 2),
+                         "single_frame_launch_frac": round(ALG_BYTES / (passes[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "every pass of this chain is bound by instruction throughput (fetch + VALU issue), "
                                  "not by bandwidth: DESIGN.md 5"},
+            "whole_frame_faults": faults,
             "kernels_us_live": ({"frame_kernel": round(live[0], 2)} if whole else {f"pass{k}": round(live[k], 2) for k in range(4)}),
             "kernels_us_isolated": ({"frame_kernel": round(passes[0], 2)} if whole else
                                     {f"pass{k}": round(passes[k], 2) for k in range(4)}),

@@ -217,6 +217,28 @@ int mi_isp_pipeline12_reinhard_whole_frame(const uint8_t* packed_dev, void* out_
                                            float intensity, float light_adapt, float color_adapt, void* ws_dev,
                                            void* stream);
 int mi_isp_pipeline12_whole_frame_fits(int H, int W, int out_dtype);
+/* n_frames frames (same size, parameters and pattern) through ONE launch of that kernel per 64 frames: the grid stays
+ * resident and walks through the frames, so dispatch, the decode table, drain and launch gap are paid per launch, not
+ * per frame (test/pipeline.py:26-32 per frame, as above).  packed_host / out_host: host arrays of n_frames device
+ * pointers; ws_dev: n_frames consecutive workspaces (mi_isp_workspace_bytes each, zero-filled once), one per frame. */
+int mi_isp_pipeline12_reinhard_whole_frame_batch(const uint8_t* const* packed_host, void* const* out_host, int n_frames,
+                                                 int H, int W, int ids_format, int pattern, const float* ccm9_host,
+                                                 int out_dtype, float gamma, float intensity, float light_adapt,
+                                                 float color_adapt, void* ws_dev, void* stream);
+/* What happens when the whole-frame kernel cannot have the chip to itself (a foreign kernel, another process): a wave
+ * whose peers do not arrive within the poll budget gives up - the frame is INVALID, nothing hangs - and says so twice:
+ *   - the frame's workspace: the 32-bit word at mi_isp_workspace_error_offset() is set (sticky until cleared);
+ *   - a host-mapped mailbox word per device, visible to the host WITHOUT synchronising: mi_isp_whole_frame_faults().
+ * mi_isp_workspace_check: synchronises `stream`, reports per frame whether its word is set (failed_host[i] = 0 / 1, may
+ *   be NULL), clears the set words and returns their number in *n_failed.  The caller re-issues the failed frames
+ *   through mi_isp_pipeline12_reinhard (the multi-pass chain needs no co-residency); taichi_image_amd.pipeline does.
+ * mi_isp_whole_frame_faults(clear): the mailbox of the current device - non-zero when any whole-frame launch of this
+ *   process on this device has timed out since it was last cleared; a plain host read.
+ * mi_isp_whole_frame_set_poll_limit(polls): the poll budget of the following launches (0 = the default, ~100 ms);
+ *   a diagnostic knob - tests/ use a budget of 1 to provoke the fault path. */
+int mi_isp_workspace_check(void* ws_dev, int n_frames, int H, int W, int* failed_host, int* n_failed, void* stream);
+int mi_isp_whole_frame_faults(int clear);
+int mi_isp_whole_frame_set_poll_limit(unsigned polls);
 
 /* The same for n_frames independent frames, frame i on streams_host[i % n_streams]
  * (one frame per stream in flight); ws_dev holds n_frames consecutive workspaces;
@@ -235,7 +257,7 @@ int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed_host, void* co
  * frame i on stream i % n_streams, join - and instantiates it; launch() replays it on `stream` (stream-ordered like any
  * other call; a replay has no launch gaps between the dependent kernels of a stream); destroy() frees it.  The buffers
  * must keep their addresses for the lifetime of the graph; ws_dev holds n_frames workspaces (zero-filled once).
- * whole_frame != 0: every frame through mi_isp_pipeline12_reinhard_whole_frame, one after the other. */
+ * whole_frame != 0: the frames through mi_isp_pipeline12_reinhard_whole_frame_batch (one launch, frames one after the other). */
 int mi_isp_pipeline12_graph_create(const uint8_t* const* packed_dev, void* const* out_dev, void* const* work_images_dev,
                                    int n_frames, int H, int W, int ids_format, int pattern, const float* ccm9_host,
                                    int work_dtype, int out_dtype, float gamma, float intensity, float light_adapt,

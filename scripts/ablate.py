@@ -9,7 +9,7 @@ H, W = 3072, 4096
 dev = torch.device("cuda", 0)
 frame = torch.from_numpy(synthetic.synthetic_packed12(0)).to(dev)
 out = torch.empty((H, W, 3), dtype=torch.float16, device=dev)
-pipeline12_reinhard(frame, out=out)
+pipeline12_reinhard(frame, out=out, whole_frame=False)
 ws = _native.workspace(H, W, dev)
 L = _native.lib()
 st = torch.cuda.current_stream(dev)

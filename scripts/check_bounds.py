@@ -8,7 +8,7 @@ from taichi_image_amd.pipeline import pipeline12_reinhard
 dev = torch.device("cuda", 0)
 for k in range(6):
     frame = torch.from_numpy(synthetic.synthetic_packed12(k)).to(dev)
-    out = pipeline12_reinhard(frame)
+    out = pipeline12_reinhard(frame, whole_frame=False)
     torch.cuda.synchronize()
     ws = _native.workspace(3072, 4096, dev)
     fp = ws.cpu().numpy().view(np.float32)[:20]

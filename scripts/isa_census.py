@@ -49,7 +49,7 @@ def main():
                "-fno-slp-vectorize", "-S", "--cuda-device-only", "-DMI_MEGA_CENSUS", *extra, os.path.join(CSRC, "isp_mega_p0.hip"), "-o", out]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
-    name = "_ZN4mega12frame_kernelILi0ELi0ELb0EEEvNS_5MArgsE"
+    name = "_ZN4mega12frame_kernelILi0ELi0ELb0EEEvNS_6MBatchE"
     body = text[text.index(name + ":"):]
     body = body[:body.index(".Lfunc_end0:")]
     lines = body.splitlines()

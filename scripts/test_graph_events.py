@@ -9,7 +9,7 @@ H, W = 3072, 4096
 dev = torch.device("cuda", 0)
 L = _native.lib()
 frames = [torch.from_numpy(synthetic.synthetic_packed12(i % 2)).to(dev) for i in range(8)]
-bp = BatchPipeline(8, H, W, dev, n_streams=2)
+bp = BatchPipeline(8, H, W, dev, n_streams=2, whole_frame=False)
 bp(frames); torch.cuda.synchronize()
 _native.check(L.mi_isp_profile_enable(64, 3))
 g = torch.cuda.CUDAGraph()

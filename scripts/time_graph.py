@@ -9,7 +9,7 @@ H, W = 3072, 4096
 dev = torch.device("cuda", 0)
 for n_streams in (1, 2, 3):
     frames = [torch.from_numpy(synthetic.synthetic_packed12(i % 2)).to(dev) for i in range(8)]
-    bp = BatchPipeline(8, H, W, dev, n_streams=n_streams)
+    bp = BatchPipeline(8, H, W, dev, n_streams=n_streams, whole_frame=False)
     for _ in range(3): bp(frames)
     torch.cuda.synchronize()
     def timeit(fn, n=30):

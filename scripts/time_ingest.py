@@ -26,7 +26,7 @@ def run(pageable):
         if pageable:
             slot.host[:] = src[i & 1].reshape(-1)
         d = slot.commit()
-        pipeline12_reinhard(d.view(H, W * 3 // 2), out=outs[i % n_slots])
+        pipeline12_reinhard(d.view(H, W * 3 // 2), out=outs[i % n_slots], whole_frame=False)
         slot.release()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -9,7 +9,7 @@ H, W = 3072, 4096
 dev = torch.device("cuda", 0)
 frame = torch.from_numpy(synthetic.synthetic_packed12(0)).to(dev)
 out = torch.empty((H, W, 3), dtype=torch.float16, device=dev)
-pipeline12_reinhard(frame, out=out)
+pipeline12_reinhard(frame, out=out, whole_frame=False)
 ws = _native.workspace(H, W, dev)
 L = _native.lib()
 st = torch.cuda.current_stream(dev)
@@ -25,10 +25,10 @@ def t(code, reps=50):
     return e0.elapsed_time(e1) * 1e3 / reps
 print("PULL_DEBUG =", os.environ.get("MI_ISP_PULL_DEBUG"), " ".join(f"pass{p}: {t(p):.1f} us" for p in range(4)), flush=True)
 def full(reps=50):
-    for _ in range(5): pipeline12_reinhard(frame, out=out)
+    for _ in range(5): pipeline12_reinhard(frame, out=out, whole_frame=False)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
-    for _ in range(reps): pipeline12_reinhard(frame, out=out)
+    for _ in range(reps): pipeline12_reinhard(frame, out=out, whole_frame=False)
     e1.record(st); e1.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 print(f"whole frame, one stream: {full():.1f} us", flush=True) if not os.environ.get("MI_ISP_PULL_DEBUG") else None

@@ -10,7 +10,7 @@ H, W = 3072, 4096
 dev = torch.device("cuda", 0)
 frame = torch.from_numpy(synthetic.synthetic_packed12(0)).to(dev)
 out = torch.empty((H, W, 3), dtype=torch.float16, device=dev)
-pipeline12_reinhard(frame, out=out)
+pipeline12_reinhard(frame, out=out, whole_frame=False)
 ws = _native.workspace(H, W, dev)
 L = _native.lib()
 st = torch.cuda.current_stream(dev)
@@ -27,5 +27,5 @@ def one_pass(code):
 isp = ti.Camera16(ti.BayerPattern.RGGB, device=dev)
 tag = os.environ.get("MI_ISP_STREAM_WAVES", "default")
 print(f"waves={tag}", " ".join(f"pass{p}: {timeit(one_pass(p)):.1f}" for p in range(4)),
-      f"frame: {timeit(lambda: pipeline12_reinhard(frame, out=out)):.1f}",
+      f"frame: {timeit(lambda: pipeline12_reinhard(frame, out=out, whole_frame=False)):.1f}",
       f"load_packed12: {timeit(lambda: isp.load_packed12(frame)):.1f} us", flush=True)

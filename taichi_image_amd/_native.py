@@ -71,6 +71,11 @@ SIGNATURES = {
     "mi_isp_pipeline12_reinhard_whole_frame": (c_int, [_P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_float, c_float,
                                                c_float, c_float, _P, _P]),
     "mi_isp_pipeline12_whole_frame_fits": (c_int, [c_int, c_int, c_int]),
+    "mi_isp_pipeline12_reinhard_whole_frame_batch": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, c_int,
+                                                             POINTER(c_float), c_int, c_float, c_float, c_float, c_float, _P, _P]),
+    "mi_isp_workspace_check": (c_int, [_P, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), _P]),
+    "mi_isp_whole_frame_faults": (c_int, [c_int]),
+    "mi_isp_whole_frame_set_poll_limit": (c_int, [ctypes.c_uint]),
     "mi_isp_workspace_error_offset": (ctypes.c_size_t, [c_int, c_int]),
     "mi_isp_profile_enable": (c_int, [c_int, c_int]),
     "mi_isp_profile_collect": (c_int, [POINTER(c_float), POINTER(c_int)]),   # float[4]
@@ -171,6 +176,8 @@ def workspace(H: int, W: int, device: torch.device, slots: int = 1) -> torch.Ten
         ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # arrival counters start at 0
         _ws_cache[key] = ws
     return ws
+
+
 
 
 def ptr_array(tensors):

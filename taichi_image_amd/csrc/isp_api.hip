@@ -300,81 +300,107 @@ static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, fl
 }
 
 // ---- the whole-frame kernel (isp_mega.h) --------------------------------------------------------------------------
-namespace mega { int blocks_per_cu(); }
-
-// Two whole-frame kernels must never share the chip: each needs every one of its blocks resident for its grid
-// barriers, and two half-resident grids would wait for each other (the kernel's bounded poll would turn that into an
-// error flag, not a hang - but the frame would be lost).  Launches on ONE stream are ordered by the stream; when a launch
-// comes on another stream than the previous one, an event is recorded behind the previous stream's work and the new
-// stream waits for it (nothing is recorded or waited for while the caller stays on one stream: two runtime calls per
-// frame less, 61 -> 58 us per frame launch by launch).
+// Two whole-frame grids must never share the chip: each needs every one of its blocks resident for its grid barriers,
+// and two half-resident grids would wait for each other (the kernel's bounded poll would turn that into an error flag,
+// not a hang - but the frames would be lost).  Launches on ONE stream are ordered by the stream.  Across streams the
+// library orders them itself: under one lock per process it makes the new stream wait for an event the library
+// recorded right behind the previous whole-frame launch, launches, and records that event again - the lock is held
+// over all three, so two threads cannot interleave (round 2 released it before the launch: a second thread could
+// record "done" ahead of the first thread's kernel).  The previous caller's stream handle is only ever compared, never
+// used.  Launches captured by the CALLER into a graph of his own are not ordered by the library (nothing can be waited
+// for at capture time): he must keep them off parallel branches, and replays of such a graph must not run beside
+// direct launches on other streams.  Other PROCESSES on the same GPU are invisible to all of this: a foreign kernel that
+// holds CUs makes the barrier time out - which is what the fault word, the mailbox and the multi-pass fallback are for.
 static struct {
   std::mutex mu;
   hipEvent_t done[16] = {};
   hipStream_t last[16] = {};
   bool has_last[16] = {};
   int n_cus[16] = {};
-  int per_cu = -1;
+  int per_cu[4] = {-1, -1, -1, -1};          // per CFA pattern: the allocator's outcome differs per instantiation
+  unsigned* mailbox_host[16] = {};           // host-mapped word per device: the kernel stores here when a barrier times out
+  unsigned* mailbox_dev[16] = {};
+  unsigned poll_limit = 0;                   // 0 = default
 } g_mega;
 
-// Called with the stream a whole-frame grid is about to be launched on (directly or inside a replayed graph).
-static int mega_order_stream(int dev, hipStream_t s) {
-  std::lock_guard<std::mutex> lock(g_mega.mu);
-  if (g_mega.has_last[dev] && g_mega.last[dev] != s) {
-    if (!g_mega.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_mega.done[dev], hipEventDisableTiming));
-    if (hipEventRecord(g_mega.done[dev], g_mega.last[dev]) == hipSuccess) {
-      MI_HIP(hipStreamWaitEvent(s, g_mega.done[dev], 0));
-    } else {                                                 // the previous stream is gone: everything it held has to be over
-      (void)hipGetLastError();
-      MI_HIP(hipDeviceSynchronize());
-    }
+// callers hold g_mega.mu
+static int mega_mailbox_locked(int dev) {
+  if (!g_mega.mailbox_host[dev]) {
+    void* h = nullptr;
+    MI_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
+    memset(h, 0, 64);
+    void* d = nullptr;
+    MI_HIP(hipHostGetDevicePointer(&d, h, 0));
+    g_mega.mailbox_host[dev] = static_cast<unsigned*>(h);
+    g_mega.mailbox_dev[dev] = static_cast<unsigned*>(d);
   }
-  g_mega.last[dev] = s; g_mega.has_last[dev] = true;
   return 0;
 }
 
-static bool mega_fits(const tile::Params& p, int work_dtype, const void* out, int out_dtype, strm::SArgs& a) {
+static bool mega_fits(const tile::Params& p, int work_dtype, const void* out, int out_dtype, int pattern, strm::SArgs& a) {
   if (work_dtype != MI_F16 || mi_dtype_size(out_dtype) > 2) return false;
   if (!use_stream(p, work_dtype, out, out_dtype) || !p.vec_store) return false;
+  if (pattern < 0 || pattern > 3) return false;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
   std::lock_guard<std::mutex> lock(g_mega.mu);
-  if (g_mega.per_cu < 0) g_mega.per_cu = mega::blocks_per_cu();
+  if (g_mega.per_cu[pattern] < 0) g_mega.per_cu[pattern] = mega::blocks_per_cu(pattern);
   if (g_mega.n_cus[dev] == 0) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
     g_mega.n_cus[dev] = n;
   }
-  return g_mega.per_cu >= 2 && mega::geometry(p.H, p.W, g_mega.n_cus[dev], a);
+  // fewer than two resident blocks per CU (a spilling or fatter instantiation) would deadlock the barrier: refuse
+  return g_mega.per_cu[pattern] >= 2 && mega::geometry(p.H, p.W, g_mega.n_cus[dev], a);
 }
 
-static int pipeline_frame_mega(tile::Params p, strm::SArgs a, int pattern, float intensity, float* ws, hipStream_t s) {
-  p.fp = ws; p.partials = ws + FP_COUNT; p.part_stride = mi_partial_cap(p.H, p.W);
+// One launch for frames [0, n): same geometry and parameters, frame i reads srcs[i], writes dsts[i] and owns the workspace
+// ws + i * ws_floats.  Ordered against the previous whole-frame launch of this process on this device (see above).
+static int mega_launch_frames(tile::Params p, strm::SArgs a, int pattern, float intensity, const uint8_t* const* srcs,
+                              void* const* dsts, float* ws, size_t ws_floats, int n, hipStream_t s) {
+  p.src = nullptr; p.dst = nullptr; p.fp = nullptr; p.partials = nullptr;
+  p.part_stride = mi_partial_cap(p.H, p.W);
   a.t = p;
-  a.n_px = (float)((int64_t)p.H * p.W); a.intensity = intensity; a.fp_w = ws; a.bounds_post = 2;
-  mega::MArgs m = {};
-  m.s = a;
-  m.fpw = reinterpret_cast<unsigned*>(ws);
-  m.spin_limit = 100000;                                  // ~100 ms of polling before a wave gives up
-  m.l2_first = 1;
-  m.poll_sleep = 0;                                       // extra 512-cycle naps between two polls (swept: 0 is best)
-#ifdef MI_ISP_MEASURE
-  if (getenv("MI_ISP_POLL_SLEEP")) m.poll_sleep = (unsigned)atoi(getenv("MI_ISP_POLL_SLEEP"));
-  if (getenv("MI_ISP_L2_FIRST")) m.l2_first = (unsigned)atoi(getenv("MI_ISP_L2_FIRST"));
-#endif
+  a.n_px = (float)((int64_t)p.H * p.W); a.intensity = intensity; a.fp_w = nullptr; a.bounds_post = 2;
   int dev = 0;
   MI_HIP(hipGetDevice(&dev));
+  MI_REQUIRE(dev >= 0 && dev < 16, "whole-frame kernel: device index %d out of range", dev);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cap);
-  if (cap != hipStreamCaptureStatusNone) return mega::launch(m, pattern, s);   // inside a graph: the capturer orders the frames
-  const PassTimer tm = pass_timer(s);                        // measurement aid: the kernel as "pass 0"
-  if (int rc = mega_order_stream(dev, s)) return rc;
-  if (int rc = tm.begin(0)) return rc;
-  if (int rc = mega::launch(m, pattern, s)) return rc;
-  if (int rc = tm.end(0)) return rc;
-  for (int k = 1; k < 4; ++k) {                              // the other three slots of the sampled frame: zero-length
-    if (int rc = tm.begin(k)) return rc;
-    if (int rc = tm.end(k)) return rc;
+  std::lock_guard<std::mutex> lock(g_mega.mu);
+  if (int rc = mega_mailbox_locked(dev)) return rc;
+  mega::MBatch mb = {};
+  mb.m.s = a;
+  mb.m.spin_limit = g_mega.poll_limit ? g_mega.poll_limit : 100000;   // ~100 ms of polling before a wave gives up
+  mb.m.l2_first = 1;
+  mb.m.poll_sleep = 0;                                       // extra 512-cycle naps between two polls (swept: 0 is best)
+  mb.m.mailbox = g_mega.mailbox_dev[dev];
+#ifdef MI_ISP_MEASURE
+  if (getenv("MI_ISP_POLL_SLEEP")) mb.m.poll_sleep = (unsigned)atoi(getenv("MI_ISP_POLL_SLEEP"));
+  if (getenv("MI_ISP_L2_FIRST")) mb.m.l2_first = (unsigned)atoi(getenv("MI_ISP_L2_FIRST"));
+#endif
+  const bool direct = cap == hipStreamCaptureStatusNone;
+  if (direct && g_mega.has_last[dev] && g_mega.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, g_mega.done[dev], 0));
+  const PassTimer tm = direct ? pass_timer(s) : PassTimer{0, false, s};   // measurement aid: a launch as "pass 0"
+  for (int i0 = 0; i0 < n; i0 += mega::MAX_BATCH) {
+    mb.n_frames = n - i0 < mega::MAX_BATCH ? n - i0 : mega::MAX_BATCH;
+    for (int i = 0; i < mb.n_frames; ++i) {
+      mb.io[i].src = srcs[i0 + i];
+      mb.io[i].dst = dsts[i0 + i];
+      mb.io[i].ws = ws + (size_t)(i0 + i) * ws_floats;
+    }
+    if (int rc = tm.begin(0)) return rc;
+    if (int rc = mega::launch(mb, pattern, s)) return rc;
+    if (int rc = tm.end(0)) return rc;
+    for (int k = 1; k < 4; ++k) {                            // the other three slots of the sampled launch: zero-length
+      if (int rc = tm.begin(k)) return rc;
+      if (int rc = tm.end(k)) return rc;
+    }
+  }
+  if (direct) {
+    if (!g_mega.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_mega.done[dev], hipEventDisableTiming));
+    MI_HIP(hipEventRecord(g_mega.done[dev], s));
+    g_mega.last[dev] = s; g_mega.has_last[dev] = true;
   }
   return 0;
 }
@@ -382,6 +408,46 @@ static int pipeline_frame_mega(tile::Params p, strm::SArgs a, int pattern, float
 extern "C" size_t mi_isp_workspace_error_offset(int H, int W) {
   if (H <= 0 || W <= 0) return 0;
   return (size_t)mega::FP_ERROR * sizeof(float);
+}
+
+extern "C" int mi_isp_whole_frame_set_poll_limit(unsigned polls) {
+  std::lock_guard<std::mutex> lock(g_mega.mu);
+  g_mega.poll_limit = polls;
+  return 0;
+}
+
+extern "C" int mi_isp_whole_frame_faults(int clear) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  std::lock_guard<std::mutex> lock(g_mega.mu);
+  if (!g_mega.mailbox_host[dev]) return 0;
+  volatile unsigned* mb = g_mega.mailbox_host[dev];
+  const unsigned v = *mb;
+  if (clear) *mb = 0;
+  return (int)v;
+}
+
+extern "C" int mi_isp_workspace_check(void* ws_dev, int n_frames, int H, int W, int* failed_host, int* n_failed,
+                                      void* stream) {
+  MI_REQUIRE(ws_dev && n_failed, "workspace_check: null pointer");
+  MI_REQUIRE(n_frames >= 0, "workspace_check: negative frame count");
+  const size_t ws_bytes = mi_isp_workspace_bytes(H, W);
+  MI_REQUIRE(ws_bytes > 0, "workspace_check: bad frame size");
+  MI_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int bad = 0;
+  for (int i = 0; i < n_frames; ++i) {
+    unsigned* w = reinterpret_cast<unsigned*>(static_cast<char*>(ws_dev) + (size_t)i * ws_bytes) + mega::FP_ERROR;
+    unsigned v = 0;
+    MI_HIP(hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost));
+    if (failed_host) failed_host[i] = v != 0;
+    if (v != 0) {
+      ++bad;
+      v = 0;
+      MI_HIP(hipMemcpy(w, &v, sizeof(v), hipMemcpyHostToDevice));   // the word is sticky in the kernel: cleared here
+    }
+  }
+  *n_failed = bad;
+  return 0;
 }
 
 // The same chain on the streaming kernels: every pass re-derives the demosaiced image from the packed frame
@@ -462,11 +528,13 @@ static int pipeline12_frame(const uint8_t* packed, void* out, void* work_image, 
   p.vec_store = vec_store_ok(out, W, out_dtype);
   if (whole_frame) {
     strm::SArgs ma = {};
-    MI_REQUIRE(mega_fits(p, work_dtype, out, out_dtype, ma),
+    MI_REQUIRE(mega_fits(p, work_dtype, out, out_dtype, pattern, ma),
                "%s: the whole-frame kernel takes f16 work dtype, u8 / u16 / f16 outputs, the standard 12-bit layout with "
                "W %% 8 == 0 and 16-byte aligned buffers, and at most 2 x CUs x 4 waves of 512 x 12 pixels (4096 x 3072 on "
                "MI355X); use mi_isp_pipeline12_reinhard for this frame", who);
-    return pipeline_frame_mega(p, ma, pattern, intensity, ws, s);
+    const uint8_t* srcs[1] = {packed};
+    void* dsts[1] = {out};
+    return mega_launch_frames(p, ma, pattern, intensity, srcs, dsts, ws, 0, 1, s);
   }
   if (use_stream(p, work_dtype, out, out_dtype) && p.vec_store && !force_cached())
     return pipeline_frame_stream(p, pattern, work_dtype, intensity, ws, -1, s);
@@ -502,7 +570,37 @@ extern "C" int mi_isp_pipeline12_whole_frame_fits(int H, int W, int out_dtype) {
   tile::Params p = {};
   p.H = H; p.W = W; p.src_kind = tile::SRC_PACKED12; p.src_fast = 1; p.in_scale = 1.f; p.vec_store = 1;
   strm::SArgs a = {};
-  return H > 0 && W > 0 && H % 2 == 0 && mi_valid_dtype(out_dtype) && mega_fits(p, MI_F16, nullptr, out_dtype, a) ? 1 : 0;
+  // asked without a pattern: all four instantiations must be launchable
+  if (!(H > 0 && W > 0 && H % 2 == 0 && mi_valid_dtype(out_dtype))) return 0;
+  for (int pat = 0; pat < 4; ++pat)
+    if (!mega_fits(p, MI_F16, nullptr, out_dtype, pat, a)) return 0;
+  return 1;
+}
+
+// n_frames frames through ONE launch of the whole-frame kernel per 64 frames (isp_mega.h: the grid stays resident and
+// walks through the frames), in order, on `stream`.
+extern "C" int mi_isp_pipeline12_reinhard_whole_frame_batch(const uint8_t* const* packed, void* const* out, int n_frames,
+                                                            int H, int W, int ids_format, int pattern, const float* ccm9,
+                                                            int out_dtype, float gamma, float intensity, float light_adapt,
+                                                            float color_adapt, void* ws, void* stream) {
+  const char* who = "pipeline12_reinhard_whole_frame_batch";
+  MI_REQUIRE(packed && out && ws, "%s: null pointer", who);
+  MI_REQUIRE(n_frames >= 1, "%s: need at least one frame", who);
+  tile::Params p = {};
+  strm::SArgs ma = {};
+  for (int i = 0; i < n_frames; ++i) {
+    MI_REQUIRE(packed[i] && out[i], "%s: frame %d has a null buffer", who, i);
+    tile::Params pi = {};
+    if (int rc = pipeline_params(pi, H, W, ids_format, pattern, ccm9, MI_F16, out_dtype, gamma, light_adapt, color_adapt)) return rc;
+    if (int rc = packed_params(pi, packed[i], H, W, 12, ids_format, MI_F16, who)) return rc;
+    pi.dst = out[i];
+    pi.vec_store = vec_store_ok(out[i], W, out_dtype);
+    MI_REQUIRE(mega_fits(pi, MI_F16, out[i], out_dtype, pattern, ma),
+               "%s: frame %d does not fit the whole-frame kernel (see mi_isp_pipeline12_reinhard_whole_frame)", who, i);
+    if (i == 0) p = pi;
+  }
+  return mega_launch_frames(p, ma, pattern, intensity, packed, out, static_cast<float*>(ws),
+                            mi_isp_workspace_bytes(H, W) / sizeof(float), n_frames, (hipStream_t)stream);
 }
 
 extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, void* const* out,
@@ -598,7 +696,17 @@ extern "C" int mi_isp_pipeline12_graph_create(const uint8_t* const* packed, void
   }
   BatchGraph* b = new BatchGraph();
   b->whole_frame = whole_frame != 0;
-  auto fail = [&](int rc) { batch_graph_free(b); return rc; };
+  bool capturing = false;
+  auto fail = [&](int rc) {
+    if (capturing) {                                         // a capture must be ended (and its graph dropped) before its stream goes
+      hipGraph_t dead = nullptr;
+      (void)hipStreamEndCapture(b->streams[0], &dead);
+      if (dead) (void)hipGraphDestroy(dead);
+      (void)hipGetLastError();
+    }
+    batch_graph_free(b);
+    return rc;
+  };
 #define MI_HIP_G(expr)                                                                              \
   do {                                                                                              \
     hipError_t e_ = (expr);                                                                         \
@@ -619,15 +727,21 @@ extern "C" int mi_isp_pipeline12_graph_create(const uint8_t* const* packed, void
   }
   hipStream_t s0 = b->streams[0];
   MI_HIP_G(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
+  capturing = true;
   MI_HIP_G(hipEventRecord(b->events[0], s0));                                   // fork
   for (int i = 1; i < n_streams; ++i) MI_HIP_G(hipStreamWaitEvent(b->streams[i], b->events[0], 0));
   const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
   int rc = 0;
-  for (int i = 0; i < n_frames && rc == 0; ++i) {
-    float* wsi = static_cast<float*>(ws) + (size_t)i * ws_floats;
-    rc = pipeline12_frame(packed[i], out[i], work_images ? work_images[i] : nullptr, H, W, ids_format, pattern, ccm9,
-                          work_dtype, out_dtype, gamma, intensity, light_adapt, color_adapt, wsi,
-                          b->streams[i % n_streams], "pipeline12_graph_create", whole_frame);
+  if (whole_frame) {
+    rc = mi_isp_pipeline12_reinhard_whole_frame_batch(packed, out, n_frames, H, W, ids_format, pattern, ccm9, out_dtype, gamma,
+                                                      intensity, light_adapt, color_adapt, ws, s0);
+  } else {
+    for (int i = 0; i < n_frames && rc == 0; ++i) {
+      float* wsi = static_cast<float*>(ws) + (size_t)i * ws_floats;
+      rc = pipeline12_frame(packed[i], out[i], work_images ? work_images[i] : nullptr, H, W, ids_format, pattern, ccm9,
+                            work_dtype, out_dtype, gamma, intensity, light_adapt, color_adapt, wsi,
+                            b->streams[i % n_streams], "pipeline12_graph_create", 0);
+    }
   }
   for (int i = 1; i < n_streams; ++i) {                                          // join
     (void)hipEventRecord(b->events[i], b->streams[i]);
@@ -635,6 +749,7 @@ extern "C" int mi_isp_pipeline12_graph_create(const uint8_t* const* packed, void
   }
   hipGraph_t g = nullptr;
   const hipError_t ec = hipStreamEndCapture(s0, &g);
+  capturing = false;
   b->graph = g;
   if (rc != 0) return fail(rc);
   if (ec != hipSuccess) { mi_set_error("pipeline12_graph_create: capture failed: %s", hipGetErrorString(ec)); return fail(2); }
@@ -650,7 +765,15 @@ extern "C" int mi_isp_pipeline12_graph_launch(void* handle, void* stream) {
   if (b->whole_frame) {                                      // its grids need the chip to themselves, like a direct launch
     int dev = 0;
     MI_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 16) { if (int rc = mega_order_stream(dev, (hipStream_t)stream)) return rc; }
+    MI_REQUIRE(dev >= 0 && dev < 16, "pipeline12_graph_launch: device index %d out of range", dev);
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_mega.mu);             // order, launch and record under one lock (see g_mega)
+    if (g_mega.has_last[dev] && g_mega.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, g_mega.done[dev], 0));
+    MI_HIP(hipGraphLaunch(b->exec, s));
+    if (!g_mega.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_mega.done[dev], hipEventDisableTiming));
+    MI_HIP(hipEventRecord(g_mega.done[dev], s));
+    g_mega.last[dev] = s; g_mega.has_last[dev] = true;
+    return 0;
   }
   MI_HIP(hipGraphLaunch(b->exec, (hipStream_t)stream));
   return 0;

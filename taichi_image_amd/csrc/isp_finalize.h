@@ -75,7 +75,9 @@ MI_DEV void finalize_scalars(int mode, const FinArgs& a, const double* tot) {
     }
     default: {
       const float LN2 = 0.6931471805599453f;
-      // lo/hi here are min/max of max(gray,1e-4)
+      // lo/hi here are min/max of max(gray,1e-4); producers that post the raw gray bounds (the whole-frame kernel) rely
+      // on this clamp (monotone, so max of the reduced value == reduced max), for the others it is the identity
+      lo = fmaxf(lo, 1e-4f); hi = fmaxf(hi, 1e-4f);
       const float lmin = HW ? __builtin_amdgcn_logf(lo) * LN2 : logf(lo);
       const float lmax = HW ? __builtin_amdgcn_logf(hi) * LN2 : logf(hi);
       const float slog = (float)(tot[2] * 0.6931471805599453);

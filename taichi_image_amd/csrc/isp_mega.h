@@ -42,14 +42,22 @@ using namespace strm;
 // Reading aid (scripts/isa_census.py compiles isp_mega_p0.hip with -DMI_MEGA_CENSUS to assembly): the run-time choices
 // of the headline configuration become constants (interior band, no colour matrix, bounds (0, 1), color_adapt == 0, f16
 // output) so that each phase is one straight-line stretch between two "; MI_MARK n" comments.  Never part of the library.
-#ifdef MI_MEGA_CENSUS
+#if defined(MI_MEGA_CENSUS)
 #define MI_CENSUS(expr, val) (val)
-#undef MI_SSTAMP
-#define MI_SSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MI_MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define MI_CMARK(i) MI_SSTAMP(i)
+#define MI_MSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MI_MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MI_CMARK(i) MI_MSTAMP(i)
 #else
 #define MI_CENSUS(expr, val) (expr)
 #define MI_CMARK(i) do {} while (0)
+#if defined(MI_STREAM_STAMPS)           /* the stamps of a frame go behind the partial rows of ITS workspace */
+#define MI_MSTAMP(i)                                                                                          \
+  do {                                                                                                        \
+    if (lane == 0 && wave_ok)                                                                                 \
+      reinterpret_cast<unsigned*>(partials + (size_t)PART_ROWS * p.part_stride)[g * 16 + (i)] = MI_STAMP_NOW();  \
+  } while (0)
+#else
+#define MI_MSTAMP(i) do {} while (0)
+#endif
 #endif
 
 constexpr int ROWS = 12;             // rows per wave
@@ -75,11 +83,27 @@ static_assert(REC >= 48 && REC % 16 == 0, "three 16-byte chunks per record");
 constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
 
 struct MArgs {
-  SArgs s;
-  unsigned* fpw;                     // FrameParams as words (FP_EPOCH, FP_ERROR)
+  SArgs s;                           // geometry and parameters shared by the frames of a launch (s.t.src / dst / fp / partials
+                                     // and s.fp_w are per frame: FrameIO)
   unsigned spin_limit;               // polls before a wave gives up (error flag, garbage frame, no hang)
   unsigned poll_sleep;               // units of 512 cycles between two polls of the partial rows
   unsigned l2_first;                 // the first round of a fold reads through the L2
+  unsigned* mailbox;                 // host-mapped word of the device: stored to when a barrier times out (no sync needed to see it)
+};
+
+// One launch takes a BATCH of frames (same size and parameters), one after the other: the grid stays resident, a wave
+// that has stored its rows of frame f goes straight on to its rows of frame f + 1.  Per launch instead of per frame:
+// dispatch, the decode table, drain and launch gap (round 2 paid ~5 us of them per frame).
+constexpr int MAX_BATCH = 64;
+struct FrameIO {
+  const void* src;                   // packed frame
+  void* dst;                         // output image
+  float* ws;                         // the frame's own workspace (FrameParams, epoch / error words, barrier records)
+};
+struct MBatch {
+  MArgs m;
+  int n_frames;
+  FrameIO io[MAX_BATCH];
 };
 
 // The block's contribution to a grid-wide reduction = its arrival at the barrier: every wave reduces in registers and
@@ -124,9 +148,10 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
 // LDS of the barrier folds: per barrier a ticket that hands out the roles, the partial folds of the four roles, a count
 // of the roles that are done and the flag the block waits for.
 struct FoldLds {
-  unsigned ticket[4], done[4], flag[4];
+  unsigned ticket[4], done[4], flag[4];   // running counts over the frames of a launch: role = ticket % WAVES, flag = frames passed
   float mm[WAVES][4];
   double sum[WAVES][5];
+  double keep[7];                         // barrier 0's totals of the speculative statistics, for barrier 1 (bounds other than (0, 1))
 };
 
 // Wait for the barrier whose records live in `area` and derive the scalars of the next phase.  Every wave of the block
@@ -139,15 +164,15 @@ struct FoldLds {
 // Plain sc1 buffer loads (aux 16), compiler-visible: an asm load would hand its destination registers back to the
 // allocator while the data is still in flight (that was a memory fault), and atomic loads are waited for one by one.
 template <int NV, int FIN>
-MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t tag, float* sh_fp, FoldLds& fl, int lane,
-                         bool rgb_sums = true, unsigned* stamps = nullptr) {
+MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const float* area, uint32_t tag, float* sh_fp,
+                         FoldLds& fl, int lane, bool rgb_sums = true, unsigned* stamps = nullptr) {
   const SArgs& a = m.s;
   constexpr int NCH = (NV + 2) / 3;
-  constexpr int NMM = NV == 9 ? 4 : 2;                // leading min / max values (alternating)
+  constexpr int NMM = NV == 9 ? 4 : (NV == 1 ? 0 : 2);   // leading min / max values (alternating)
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   unsigned role = 0;
   if (lane == 0) role = __hip_atomic_fetch_add(fl.ticket + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  role = __builtin_amdgcn_readfirstlane(role);
+  role = __builtin_amdgcn_readfirstlane(role) & (WAVES - 1);
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(area), 0, (int)((size_t)8 * a.t.part_stride * sizeof(float)), 0x00020000);
   u4 v[2][NCH];
@@ -219,12 +244,15 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t ta
     const unsigned naps = __builtin_popcountll(missing) > 16 ? 4u * m.poll_sleep + 1u : m.poll_sleep;
     for (unsigned z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
     if (++spins > m.spin_limit) {                     // a peer is not resident: give up loudly instead of hanging
-      if (lane == 0) __hip_atomic_store(m.fpw + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m.mailbox) __hip_atomic_store(m.mailbox, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       break;
     }
   }
   if (stamps && lane == 0 && role == 0) stamps[0] = MI_STAMP_NOW();
-  float mm[NMM];
+  float mm[NMM > 0 ? NMM : 1];
   double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
@@ -247,6 +275,7 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t ta
   }
 #pragma unroll
   for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? wave_max(mm[k]) : wave_min(mm[k]);
+  if (NV == 1) sum[0] = wave_sum(sum[0]);
   if (NV >= 7) {
     sum[0] = wave_sum(sum[0]); sum[1] = wave_sum(sum[1]);
     if (rgb_sums) {                                    // else they are zero
@@ -262,7 +291,7 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t ta
     for (int k = 0; k < 5; ++k) fl.sum[role][k] = sum[k];
     finished = __hip_atomic_fetch_add(fl.done + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  finished = __builtin_amdgcn_readfirstlane(finished);
+  finished = __builtin_amdgcn_readfirstlane(finished) & (WAVES - 1);
   if (stamps && lane == 0 && role == 0) stamps[1] = MI_STAMP_NOW();
   if (finished == WAVES - 1) {
     // ---- the last role combines the partial folds (role order) and publishes the scalars ----
@@ -275,29 +304,48 @@ MI_DEV void barrier_fold(const MArgs& m, int bar, const float* area, uint32_t ta
         for (int r = 1; r < WAVES; ++r) x = (k & 1) ? fmaxf(x, fl.mm[r][k]) : fminf(x, fl.mm[r][k]);
         tot[k] = (double)x;
       }
-      if (NV >= 7) {
+      if (NV >= 7 || NV == 1) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) tot[NMM + k] = ((fl.sum[0][k] + fl.sum[1][k]) + fl.sum[2][k]) + fl.sum[3][k];
+        for (int k = 0; k < (NV == 1 ? 1 : 5); ++k) tot[NMM + k] = ((fl.sum[0][k] + fl.sum[1][k]) + fl.sum[2][k]) + fl.sum[3][k];
       }
       ew::FinArgs fa = {};
       fa.fp = sh_fp; fa.n_px = a.n_px; fa.intensity = a.intensity; fa.la = a.t.la; fa.ca = a.t.ca;
       fa.bounds_post = a.bounds_post;
       if constexpr (NV == 9) {
         ew::finalize_scalars<true>(ew::FIN_BOUNDS, fa, tot);
-        if (sh_fp[FP_LO] == 0.f && sh_fp[FP_INV] == 1.f) ew::finalize_scalars<true>(ew::FIN_STATS, fa, tot + 2);
+        if (sh_fp[FP_LO] == 0.f && sh_fp[FP_INV] == 1.f) {
+          ew::finalize_scalars<true>(ew::FIN_STATS, fa, tot + 2);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) fl.keep[k] = tot[2 + k];     // raw gray min / max, (sum log2), sum gray, channel sums
+        }
+      } else if constexpr (NV == 1) {
+        // The statistics of the NORMALISED image (tonemap.py:147-149) from those of the raw one: n = (x - lo) * inv is
+        // affine, the weights of rgb_gray sum to 1, and the clamp to [0, 1] is the identity between the image's own
+        // bounds - so gray(n) = (gray(x) - lo) * inv, its min / max and every sum follow from the raw ones (within fp32
+        // rounding: ~1e-7 relative, the contract of these scalars is 1e-4); only the sum of logarithms needs the pixels
+        // (phase B: tot[0]).
+        const double lo = (double)sh_fp[FP_LO], inv = (double)sh_fp[FP_INV], n = (double)a.n_px;
+        double t7[7];
+        t7[0] = (fl.keep[0] - lo) * inv; t7[1] = (fl.keep[1] - lo) * inv;
+        t7[2] = tot[0];
+        t7[3] = (fl.keep[3] - n * lo) * inv;
+#pragma unroll
+        for (int k = 4; k < 7; ++k) t7[k] = (fl.keep[k] - n * lo) * inv;
+        ew::finalize_scalars<true>(ew::FIN_STATS, fa, t7);
       } else {
         ew::finalize_scalars<true>(FIN, fa, tot);
       }
       if (stamps) stamps[2] = MI_STAMP_NOW();
-      __hip_atomic_store(fl.flag + bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       // block 0 leaves the frame's scalars in FrameParams, as the multi-pass chain does (callers may read them back)
-      if (blockIdx.x == 0 && a.fp_w) {
-        for (int i = 0; i <= FP_MAXOUT; ++i) a.fp_w[i] = sh_fp[i];
+      if (blockIdx.x == 0) {
+        for (int i = 0; i <= FP_MAXOUT; ++i) ws[i] = sh_fp[i];
       }
     }
   } else {
     unsigned naps = 0;
-    while (__hip_atomic_load(fl.flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+    while ((int)(__hip_atomic_load(fl.flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) {
       __builtin_amdgcn_s_sleep(2);
       if (++naps > 64u * m.spin_limit) break;
     }
@@ -315,14 +363,80 @@ MI_DEV void unpack_row(const uint32_t (&pk)[12], float (&t)[24]) {
   }
 }
 
+// rgb_gray (color/__init__.py:7-10) of pixel K of a packed row, straight from the f16 halves: three v_fma_mix_f32 (the
+// half is widened exactly, the fma rounds once in fp32 - the bits of converting first and then mul / fma / fma, without
+// the three conversions).  w0..w2: the weights in VGPRs.
+template <int E> MI_DEV float fma_mix_h(uint32_t pk, float w, float acc) {
+  float r;
+  if constexpr ((E & 1) == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(w), "v"(acc));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(w), "v"(acc));
+  return r;
+}
+template <int E> MI_DEV float mul_mix_h(uint32_t pk, float w) {
+  float r;
+  if constexpr ((E & 1) == 0) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(w));
+  else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(w));
+  return r;
+}
+template <int K> MI_DEV float gray_pk(const uint32_t (&pk)[12], float w0, float w1, float w2) {
+  constexpr int e = 3 * K;
+  const float a = mul_mix_h<e>(pk[e / 2], w0);
+  const float b = fma_mix_h<e + 1>(pk[(e + 1) / 2], w1, a);
+  return fma_mix_h<e + 2>(pk[(e + 2) / 2], w2, b);
+}
+
+// "Defines" registers without an instruction.  The resident rows are written and read under wave-uniform conditions (a
+// band may end before its 12th row).  Inside the frame loop a variable that is assigned under a condition carries, for
+// the compiler, its value of the PREVIOUS frame along the other arm - all 252 registers of resident rows would be live
+// around the loop.  An unconditional (empty) definition right before the conditional one cuts that.
+// (__builtin_nondeterministic_value = a frozen undefined value: no instruction; an empty asm with an output costs a
+// v_mov and a hazard s_nop each.)
+template <class T, int N> MI_DEV void fresh(T (&x)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = __builtin_nondeterministic_value(x[i]);
+}
+
+// bounds of a packed f16 row: four values per instruction (gfx950: v_pk_minimum3_f16 / v_pk_maximum3_f16; the values are
+// clamped and finite, so the NaN rule of the IEEE-2019 minimum does not come into play)
+MI_DEV void pk_bounds_row(const uint32_t (&pk)[12], uint32_t& mn, uint32_t& mx) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    asm("v_pk_minimum3_f16 %0, %0, %1, %2" : "+v"(mn) : "v"(pk[2 * j]), "v"(pk[2 * j + 1]));
+    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(mx) : "v"(pk[2 * j]), "v"(pk[2 * j + 1]));
+  }
+}
+MI_DEV float pk_lo(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return (float)h[0]; }
+MI_DEV float pk_hi(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return (float)h[1]; }
+
+// where phase D issues the first loads of the NEXT frame of the batch: behind resident row PREFETCH_AT (registers have
+// come free by then: 24 VGPRs per retired register row)
+#ifndef MI_MEGA_D_ORDER
+#define MI_MEGA_D_ORDER 1
+#endif
+#ifndef MI_MEGA_PREFETCH_AT
+#define MI_MEGA_PREFETCH_AT 3            /* register rows first: behind LDS row 3 */
+#endif
+#ifndef MI_MEGA_PREFETCH_AT_LATE
+#define MI_MEGA_PREFETCH_AT_LATE 8       /* LDS rows first: behind register row 8 */
+#endif
+// LDS rows whose second Reinhard evaluation (it needs nothing from barrier 2) runs between a wave's post and its first
+// poll of that barrier, i.e. inside the wait for the slowest block
+#ifndef MI_MEGA_PRE2
+#define MI_MEGA_PRE2 1
+#endif
+
 // RGB: color_adapt != 0 (per-channel sums in the statistics).  Two kernels instead of a run-time flag: with both kinds of
 // statistics in one body the register allocator spilled 13 VGPRs to scratch in phase A and reloaded them in B / C / D,
-// which cost 3.3 us per frame (58.2 -> 54.9).  Split, every variant fits 252 - 256 VGPRs without scratch - as long as the
+// which cost 3.3 us per frame (58.2 -> 54.9).  Split, every variant fits 256 VGPRs without scratch - as long as the
 // Reinhard dispatch below stays a run-time branch on `ca0` (made compile-time, the RGB = false kernel spilled 17):
-// tests/test_abi.py::test_whole_frame_kernel_uses_no_scratch compiles the kernel and checks.
+// tests/test_abi.py::test_whole_frame_kernel_uses_no_scratch compiles the kernels and checks.
+// (A variant without the row conditions for frames whose height is a multiple of 12 was tried: with no branches between
+// them the phases' rows become one scheduling region, and the scheduler's reordering cost 225 - 279 spills.  The
+// conditions stay.)
 template <int PR, int PC, bool RGB>
-__global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
+__global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   typedef half_t E;
+  const MArgs& m = mb.m;
   const SArgs& a = m.s;
   const Params& p = a.t;
   __shared__ __attribute__((aligned(16))) uint4 xl[WAVES][NL][ROW_U4];   // resident rows 0..NL-1 of each wave; output staging
@@ -335,70 +449,112 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   if (threadIdx.x == 0) arrived = 0;
   if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = 0.f;
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = blockIdx.x * WAVES + wave;
-  const bool wave_ok = g < a.n_waves;
-  const int by = g / a.bands_x, bx = g - by * a.bands_x;
-  const int c0 = bx * BAND + lane * 8;
-  const int r_begin = by * ROWS;
-  const int r_end = wave_ok ? (r_begin + ROWS < p.H ? r_begin + ROWS : p.H) : r_begin;
-  const bool col_ok = wave_ok && c0 < p.W;
-  const int active_lanes = !wave_ok ? 0 : (p.W - bx * BAND >= BAND ? 64 : (p.W - bx * BAND) / 8);
-
-  const uint32_t pitch = (uint32_t)p.W * 3 / 2;
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
-  const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID_OFF;
-  const bool ext_ok = col_ok && ((lane == 0 && c0 > 0) || (lane == 63 && c0 + 8 < p.W));
-  const uint32_t ext_off = ext_ok ? (uint32_t)c0 * 3 / 2 + (lane == 0 ? -4 : 12) : INVALID_OFF;
-  auto load_row = [&](int r, uint32_t (&d)[4]) {
-    const uint32_t row_off = (r >= 0 && r < p.H && r < r_end + 2) ? (uint32_t)r * pitch : INVALID_OFF;     // scalar
-    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-    const u3 q = __builtin_amdgcn_raw_buffer_load_b96(rsrc, col_off + row_off, 0, 0);
-    d[0] = q.x; d[1] = q.y; d[2] = q.z;
-    d[3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ext_off + row_off, 0, 0);
+  // Where a wave works.  Derived twice: here for the first frame's first loads, and again at the top of every frame from
+  // laundered thread / block ids - so that NOTHING but the frame counter and the prefetched rows is live around the
+  // frame loop.  (With the geometry computed once outside, the compiler hoisted the rows' offset arithmetic out of the
+  // loop as well and the allocator, with every register taken inside the body, spilled 500 - 600 VGPRs.)
+  struct Geo {
+    int lane, wave, g, bx, c0, r_begin, r_end, active_lanes;
+    bool wave_ok, col_ok, is_left, is_right, any_left, any_right;
+    uint32_t col_off, ext_off;
   };
+  const uint32_t pitch = (uint32_t)p.W * 3 / 2;
+  auto geo = [&](int tid, int bid) {
+    Geo G;
+    G.lane = tid & 63;
+    G.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    G.g = bid * WAVES + G.wave;
+    G.wave_ok = G.g < a.n_waves;
+    const int by = G.g / a.bands_x;
+    G.bx = G.g - by * a.bands_x;
+    G.c0 = G.bx * BAND + G.lane * 8;
+    G.r_begin = by * ROWS;
+    G.r_end = G.wave_ok ? (G.r_begin + ROWS < p.H ? G.r_begin + ROWS : p.H) : G.r_begin;
+    G.col_ok = G.wave_ok && G.c0 < p.W;
+    G.active_lanes = !G.wave_ok ? 0 : (p.W - G.bx * BAND >= BAND ? 64 : (p.W - G.bx * BAND) / 8);
+    G.col_off = G.col_ok ? (uint32_t)G.c0 * 3 / 2 : INVALID_OFF;
+    const bool ext_ok = G.col_ok && ((G.lane == 0 && G.c0 > 0) || (G.lane == 63 && G.c0 + 8 < p.W));
+    G.ext_off = ext_ok ? (uint32_t)G.c0 * 3 / 2 + (G.lane == 0 ? -4 : 12) : INVALID_OFF;
+    G.is_left = G.col_ok && G.c0 == 0; G.is_right = G.col_ok && G.c0 + 8 == p.W;
+    G.any_left = __builtin_amdgcn_ballot_w64(G.is_left) != 0; G.any_right = __builtin_amdgcn_ballot_w64(G.is_right) != 0;
+    return G;
+  };
+  auto load_row = [&](const Geo& G, const __amdgpu_buffer_rsrc_t rsrc, int r, uint32_t (&d)[4]) {
+    const uint32_t row_off = (r >= 0 && r < p.H && r < G.r_end + 2) ? (uint32_t)r * pitch : INVALID_OFF;     // scalar
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const u3 q = __builtin_amdgcn_raw_buffer_load_b96(rsrc, G.col_off + row_off, 0, 0);
+    d[0] = q.x; d[1] = q.y; d[2] = q.z;
+    d[3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, G.ext_off + row_off, 0, 0);
+  };
+  auto src_rsrc = [&](const void* src) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
+  };
+  // the loads a frame starts with: the four rows above / at the top of the band and the first two row pairs
+  uint32_t pro[4][4];
+  uint32_t raw[2][2][4];                              // row pairs in flight: two bodies ahead (~8k cycles) covers the latency
+  auto first_loads = [&](const Geo& G, const void* src) {
+    const __amdgpu_buffer_rsrc_t rs = src_rsrc(src);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_row(G, rs, G.r_begin - 2 + q, pro[q]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      load_row(G, rs, G.r_begin + 2 + 2 * j, raw[j][0]);
+      load_row(G, rs, G.r_begin + 3 + 2 * j, raw[j][1]);
+    }
+  };
+#ifndef MI_MEGA_NOPREFETCH
+  first_loads(geo(threadIdx.x, blockIdx.x), mb.io[0].src);
+#endif
 
-  const uint32_t epoch = __builtin_amdgcn_readfirstlane(m.fpw[FP_EPOCH]);
+  // ---- once per launch: the decode table ----
+  for (int e = threadIdx.x; e < 4096; e += THREADS) lut[e] = tile::decode_scaled<E>((uint32_t)e, p.k_decode);
+  __syncthreads();                                    // table, tickets, flags, `arrived`: the kernel's only workgroup barrier
+  constexpr bool want_rgb = RGB;                        // the host picks the kernel by p.ca != 0
+
+  for (int f = 0; f < mb.n_frames; ++f) {
+  int tid_ = threadIdx.x, bid_ = blockIdx.x;
+  asm volatile("" : "+v"(tid_), "+s"(bid_));
+  const Geo G = geo(tid_, bid_);
+  const int lane = G.lane, wave = G.wave, g = G.g, bx = G.bx, r_begin = G.r_begin, r_end = G.r_end, active_lanes = G.active_lanes;
+  const bool wave_ok = G.wave_ok, col_ok = G.col_ok, is_left = G.is_left, is_right = G.is_right, any_left = G.any_left,
+             any_right = G.any_right;
+  // output rows leave through a buffer resource (wave_store_units): unit j * 64 + lane of the band's row
+  const int osz = (int)mi_dtype_size_dev(p.out_dtype);
+  const int unit_bytes = osz == 1 ? 8 : 16, units_per_lane = 24 * osz / unit_bytes;
+  const uint32_t out_pitch = (uint32_t)p.W * 3u * (uint32_t)osz, band_base = (uint32_t)bx * BAND * 3u * (uint32_t)osz;
+  const FrameIO io = mb.io[f];
+#ifdef MI_MEGA_NOPREFETCH
+  first_loads(G, io.src);
+#endif
+  const unsigned seq = (unsigned)f + 1u;              // what the LDS flags of this frame's barriers count up to
+  float* const ws = io.ws;
+  float* const partials = ws + FP_COUNT;
+  const __amdgpu_buffer_rsrc_t rsrc = src_rsrc(io.src);
+  const uint32_t epoch = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(ws)[FP_EPOCH]);
   const uint32_t tag = epoch + 1u == 0u ? 1u : epoch + 1u;     // never 0: a zero-filled workspace matches no launch
-  MI_SSTAMP(0);
+  MI_MSTAMP(0);
 #ifdef MI_STREAM_STAMPS
-  unsigned* st_ = nullptr;
-  if (p.partials) st_ = reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16;
+  unsigned* st_ = reinterpret_cast<unsigned*>(partials + (size_t)PART_ROWS * p.part_stride) + g * 16;
 #ifdef MI_STAMP_HWID                                     // where the wave runs: HW_ID (SE / CU / SIMD / slot) and XCC_ID
-  if (lane == 0 && wave_ok && st_) { st_[15] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); st_[14] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); }
+  if (lane == 0 && wave_ok) { st_[15] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); st_[14] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); }
 #endif
 #endif
   // ================================ phase A: demosaic once ================================
+  // The uniform operands of a phase are set up at ITS start, every frame (vgpr() is opaque, so they are neither hoisted
+  // out of the frame loop nor kept alive through the other phases: this kernel has no registers to park them in).
   float wq[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) wq[i] = vgpr(wq_value(i));
+  const float gw0 = vgpr(0.299f), gw1 = vgpr(0.587f), gw2 = vgpr(0.114f);
   WinRow win[6];
-  uint32_t raw[2][2][4];                              // row pairs in flight: two bodies ahead (~8k cycles) covers the latency
   uint32_t xr[NR][12];                                // resident rows NL..ROWS-1 (packed f16 pairs)
-  {
-    uint32_t pro[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) load_row(r_begin - 2 + q, pro[q]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      load_row(r_begin + 2 + 2 * j, raw[j][0]);
-      load_row(r_begin + 3 + 2 * j, raw[j][1]);
-    }
-    for (int e = threadIdx.x; e < 4096; e += THREADS) lut[e] = tile::decode_scaled<E>((uint32_t)e, p.k_decode);
-    __syncthreads();                                  // table, tickets, flags, `arrived`: the kernel's only workgroup barrier
-#pragma unroll
-    for (int q = 0; q < 4; ++q) decode_row(pro[q], lut, lane, win[q]);
-  }
+  for (int q = 0; q < 4; ++q) decode_row(pro[q], lut, lane, win[q]);
   MI_CMARK(10);
 #if defined(MI_STREAM_STAMPS) && !defined(MI_STAMP_HWID)
-  if (lane == 0 && wave_ok && st_) st_[15] = MI_STAMP_NOW();      // prologue done: table built, first four rows decoded
+  if (lane == 0 && wave_ok) st_[15] = MI_STAMP_NOW();      // prologue done: first four rows decoded
 #endif
-  const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
-  const bool any_left = __builtin_amdgcn_ballot_w64(is_left) != 0, any_right = __builtin_amdgcn_ballot_w64(is_right) != 0;
-  constexpr bool want_rgb = RGB;                        // the host picks the kernel by p.ca != 0
-  float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  uint32_t bmin = 0x7C007C00u, bmax = 0xFC00FC00u;    // packed f16 {+inf, +inf} / {-inf, -inf}
   Stats2 st; st.init();
 
   static_for<0, ROWS / 2>([&](auto ibc) {
@@ -407,13 +563,15 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
     decode_row(raw[IB % 2][0], lut, lane, win[(2 * PH + 4) % 6]);
     decode_row(raw[IB % 2][1], lut, lane, win[(2 * PH + 5) % 6]);
     if constexpr (IB + 2 < ROWS / 2) {
-      load_row(r + 6, raw[IB % 2][0]);
-      load_row(r + 7, raw[IB % 2][1]);
+      load_row(G, rsrc, r + 6, raw[IB % 2][0]);
+      load_row(G, rsrc, r + 7, raw[IB % 2][1]);
     }
 #if defined(MI_STREAM_STAMPS) && !defined(MI_STAMP_HWID)
-    if constexpr (IB == 3) { if (lane == 0 && wave_ok && st_) st_[14] = MI_STAMP_NOW(); }      // half of the rows done
+    if constexpr (IB == 3) { if (lane == 0 && wave_ok) st_[14] = MI_STAMP_NOW(); }      // half of the rows done
 #endif
-    if (r < r_end) {                                  // wave-uniform
+    if constexpr (2 * IB >= NL) fresh(xr[2 * IB - NL]);
+    if constexpr (2 * IB + 1 >= NL) fresh(xr[2 * IB + 1 - NL]);
+    if (r < r_end) {                          // wave-uniform
       WinRow w6[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) w6[k] = win[(2 * PH + k) % 6];
@@ -433,23 +591,23 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
               v[3 * k + ch] = (p.ccm[3 * ch] * x + p.ccm[3 * ch + 1] * y) + p.ccm[3 * ch + 2] * z;
           }
         }
-        // bounds: clamp and f16 rounding are monotone, applied once to the reduced values (bounds_post)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          vmin = fminf(vmin, fminf(v[3 * k], fminf(v[3 * k + 1], v[3 * k + 2])));
-          vmax = fmaxf(vmax, fmaxf(v[3 * k], fmaxf(v[3 * k + 1], v[3 * k + 2])));
-        }
+        // the pixel as the reference materialises it: clamped (bayer.py:155), rounded to f16
         uint32_t pk[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) pk[j] = tile::cvt_pk_f16_clamp01(v[2 * j], v[2 * j + 1]);
-        float t[24];
-        unpack_row(pk, t);
-        if (want_rgb) {
+        // bounds of the image (tonemap.py:146) on the rounded values, four per instruction
+        pk_bounds_row(pk, bmin, bmax);
+        // statistics of tonemap.py:147-149 under the assumption that the bounds are (0, 1)
+        if constexpr (want_rgb) {
+          float t[24];
+          unpack_row(pk, t);
 #pragma unroll
           for (int k = 0; k < 8; k += 2) st.add2<true>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
         } else {
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) st.add2<false>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+          static_for<0, 4>([&](auto kc) {
+            constexpr int K = 2 * decltype(kc)::value;
+            st.add2_gray(gray_pk<K>(pk, gw0, gw1, gw2), gray_pk<K + 1>(pk, gw0, gw1, gw2));
+          });
         }
         // the pixels stay on the chip
         if constexpr (RR < NL) {
@@ -465,22 +623,24 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
     }
   });
 
-  MI_SSTAMP(1);
-  float* rows_bounds = p.partials + (size_t)MROW_BAR0 * p.part_stride;
-  float* rows_stats = p.partials + (size_t)MROW_BAR1 * p.part_stride;
-  float* rows_bounds2 = p.partials + (size_t)MROW_BAR2 * p.part_stride;
+  MI_MSTAMP(1);
+  float* rows_bounds = partials + (size_t)MROW_BAR0 * p.part_stride;
+  float* rows_stats = partials + (size_t)MROW_BAR1 * p.part_stride;
+  float* rows_bounds2 = partials + (size_t)MROW_BAR2 * p.part_stride;
+  float vmin, vmax;
   {
-    st.finish();
+    // gray min / max are posted as they are: the clamp max(gray, 1e-4) of tonemap.py:86 (monotone) is applied to the
+    // reduced values by the finalize step, and the raw values serve the affine route of barrier 1
+    vmin = fminf(pk_lo(bmin), pk_hi(bmin)); vmax = fmaxf(pk_lo(bmax), pk_hi(bmax));
     if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }
     const float v9[9] = {vmin, vmax, st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[9] = {0, 1, 0, 1, 2, 2, 2, 2, 2};
     block_reduce_post<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane, tag, want_rgb ? 9 : 6);
   }
 
-  // the resident row RR as 24 fp32 values
-  auto resident = [&](auto rrc, float (&t)[24]) {
+  // the resident row RR: packed, and as 24 fp32 values
+  auto resident_pk = [&](auto rrc, uint32_t (&pk)[12]) {
     constexpr int RR = decltype(rrc)::value;
-    uint32_t pk[12];
     if constexpr (RR < NL) {
       uint4 mine[3];
 #pragma unroll
@@ -490,44 +650,49 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
 #pragma unroll
       for (int j = 0; j < 12; ++j) pk[j] = xr[RR - NL][j];
     }
+  };
+  auto resident = [&](auto rrc, float (&t)[24]) {
+    uint32_t pk[12];
+    resident_pk(rrc, pk);
     unpack_row(pk, t);
   };
 
   // ================================ barrier 0: bounds (tonemap.py:146) ================================
-  MI_SSTAMP(2);
+  MI_MSTAMP(2);
 #ifdef MI_STREAM_STAMPS
-  barrier_fold<9, ew::FIN_BOUNDS>(m, 0, rows_bounds, tag, sh_fp, fl, lane, want_rgb,
-                                  reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16 + 9);
+  barrier_fold<9, ew::FIN_BOUNDS>(m, ws, seq, 0, rows_bounds, tag, sh_fp, fl, lane, want_rgb, st_ + 9);
 #else
-  barrier_fold<9, ew::FIN_BOUNDS>(m, 0, rows_bounds, tag, sh_fp, fl, lane, want_rgb);
+  barrier_fold<9, ew::FIN_BOUNDS>(m, ws, seq, 0, rows_bounds, tag, sh_fp, fl, lane, want_rgb);
 #endif
-  MI_SSTAMP(3);
+  MI_MSTAMP(3);
   const float lo_s = sh_fp[FP_LO], inv_s = sh_fp[FP_INV];
   const bool unit = MI_CENSUS(lo_s == 0.f && inv_s == 1.f, true);
   // per-pixel operands live in VGPRs: a VALU instruction with an SGPR operand issues at half rate
   const float lo = vgpr(lo_s), inv = vgpr(inv_s);
   if (!unit) {
     // ============================ phase B: the statistics for bounds other than (0, 1) ============================
-    st.init();
+    // Only the sum of log(gray) needs the pixels again; the other statistics of the normalised image follow from the
+    // raw ones of phase A (barrier_fold<1>).  gray(n) = (gray(x) - lo) * inv: see there.
+    float sl0 = 0.f, sl1 = 0.f;
     static_for<0, ROWS>([&](auto rrc) {
       constexpr int RR = decltype(rrc)::value;
       if (r_begin + RR < r_end) {
-        float t[24], n[24];
-        resident(rrc, t);
-#pragma unroll
-        for (int j = 0; j < 24; ++j) n[j] = norm01(t[j], lo, inv);
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) st.add2<true>(n[3 * k], n[3 * k + 1], n[3 * k + 2], n[3 * k + 3], n[3 * k + 4], n[3 * k + 5]);
+        uint32_t pk[12];
+        resident_pk(rrc, pk);
+        static_for<0, 4>([&](auto kc) {
+          constexpr int K = 2 * decltype(kc)::value;
+          const float ga = (gray_pk<K>(pk, gw0, gw1, gw2) - lo) * inv, gb = (gray_pk<K + 1>(pk, gw0, gw1, gw2) - lo) * inv;
+          sl0 += hw_log2(fmaxf(ga, 1e-4f));
+          sl1 += hw_log2(fmaxf(gb, 1e-4f));
+        });
       }
     });
-    st.finish();
-    if (!col_ok) st.init();
-    const float v7[7] = {st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
-    const int op[7] = {0, 1, 2, 2, 2, 2, 2};
-    block_reduce_post<7>(v7, op, red, &arrived, rows_stats, p.part_stride, blockIdx.x, wave, lane, tag);
-    barrier_fold<7, ew::FIN_STATS>(m, 1, rows_stats, tag, sh_fp, fl, lane);
+    const float v1[1] = {col_ok ? sl0 + sl1 : 0.f};
+    const int op[1] = {2};
+    block_reduce_post<1>(v1, op, red, &arrived, rows_stats, p.part_stride, blockIdx.x, wave, lane, tag);
+    barrier_fold<1, ew::FIN_STATS>(m, ws, seq, 1, rows_stats, tag, sh_fp, fl, lane);
   }
-  MI_SSTAMP(4);
+  MI_MSTAMP(4);
   ReinhardK rk;
   const bool ca0 = MI_CENSUS(p.ca == 0.f, true);        // runtime on purpose: see the note on register allocation at the kernel's head
   rk.la = vgpr(p.la); rk.ca = vgpr(p.ca);
@@ -567,6 +732,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
   float qr_[NR][24];
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
+    if constexpr (RR >= NL) fresh(qr_[RR - NL]);
     if (r_begin + RR < r_end) {
       float t[24], q[24];
       resident(rrc, t);
@@ -582,34 +748,48 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
       }
     }
   });
-  MI_SSTAMP(5);
+  MI_MSTAMP(5);
   {
     if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); }
     const float v2[2] = {vmin, vmax};
     const int op[2] = {0, 1};
     block_reduce_post<2>(v2, op, red, &arrived, rows_bounds2, p.part_stride, blockIdx.x, wave, lane, tag);
   }
-  MI_SSTAMP(6);
+  MI_MSTAMP(6);
+  // Between the post and the first poll: the second Reinhard evaluation of the first LDS rows.  It needs nothing from
+  // the barrier, and every wave has ~2 us to wait for the last block's record anyway.
+  constexpr int PRE2 = RGB ? 0 : MI_MEGA_PRE2;          // (the color_adapt != 0 kernel has no room for it: 2 spills)
+  float qpre[PRE2 > 0 ? PRE2 : 1][24];
+  static_for<0, PRE2>([&](auto rrc) { fresh(qpre[decltype(rrc)::value]); });
+  dispatch([&](auto unit_c, auto ca0_c) {
+    static_for<0, PRE2>([&](auto rrc) {
+      constexpr int RR = decltype(rrc)::value;
+      if (r_begin + RR < r_end) {
+        float t[24];
+        resident(rrc, t);
+        tone_row(unit_c, ca0_c, t, qpre[RR]);
+      }
+    });
+  });
 #ifdef MI_STREAM_STAMPS
-  barrier_fold<2, ew::FIN_BOUNDS2>(m, 2, rows_bounds2, tag, sh_fp, fl, lane, true,
-                                   reinterpret_cast<unsigned*>(p.partials + (size_t)PART_ROWS * p.part_stride) + g * 16 + 12);
+  barrier_fold<2, ew::FIN_BOUNDS2>(m, ws, seq, 2, rows_bounds2, tag, sh_fp, fl, lane, true, st_ + 12);
 #else
-  barrier_fold<2, ew::FIN_BOUNDS2>(m, 2, rows_bounds2, tag, sh_fp, fl, lane);
+  barrier_fold<2, ew::FIN_BOUNDS2>(m, ws, seq, 2, rows_bounds2, tag, sh_fp, fl, lane);
 #endif
-  MI_SSTAMP(7);
+  MI_MSTAMP(7);
   const float lo2 = vgpr(sh_fp[FP_LO2]), inv2 = vgpr(sh_fp[FP_INV2]);
   const float out_scale = vgpr(p.out_scale);
 
   // ================================ phase D: final map (tonemap.py:154) ================================
-  const int osz = (int)mi_dtype_size_dev(p.out_dtype);
-  const int unit_bytes = osz == 1 ? 8 : 16, units_per_lane = 24 * osz / unit_bytes;
-  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.dst, 0, (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz), 0x00020000);
   uint32_t lane_off[6];
+  {
+    const int lane_d = lane;
 #pragma unroll
-  for (int j = 0; j < 6; ++j)
-    lane_off[j] = (j * 64 + lane) < active_lanes * units_per_lane ? (uint32_t)(j * 64 + lane) * unit_bytes : INVALID_OFF;
-  const uint32_t out_pitch = (uint32_t)p.W * 3u * (uint32_t)osz, band_base = (uint32_t)bx * BAND * 3u * (uint32_t)osz;
+    for (int j = 0; j < 6; ++j)
+      lane_off[j] = (j * 64 + lane_d) < active_lanes * units_per_lane ? (uint32_t)(j * 64 + lane_d) * unit_bytes : INVALID_OFF;
+  }
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
+      io.dst, 0, (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz), 0x00020000);
   auto finish_row = [&](auto rrc, float (&q)[24]) {
     constexpr int RR = decltype(rrc)::value;
     linear_n<24>(q, lo2, inv2, p.gamma_inv, out_scale);
@@ -630,31 +810,62 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MArgs m) {
       }
     }
   };
-  // the LDS rows: Reinhard again (their mapped values had no room to stay), then the register rows: only the final map
-  dispatch([&](auto unit_c, auto ca0_c) {
-    static_for<0, NL>([&](auto rrc) {
+  // Order (MI_MEGA_D_ORDER 1): the row(s) evaluated before the barrier, then the REGISTER rows - their mapped values are
+  // ready, so their 7 x 3 KB of stores per wave are under way within a microsecond and the memory system is busy from
+  // the start of the phase -, then Reinhard again for the other LDS rows (their mapped values had no room to stay) while
+  // those stores drain.  Order 0 (round 2): LDS rows first, the burst of the register rows' stores at the end.
+  constexpr bool REGS_FIRST = MI_MEGA_D_ORDER == 1 && PRE2 >= 1;   // (row 0's slot, the register rows' staging, must be free)
+  auto lds_rows = [&]() {
+    dispatch([&](auto unit_c, auto ca0_c) {
+      static_for<PRE2, NL>([&](auto rrc) {
+        constexpr int RR = decltype(rrc)::value;
+        if (r_begin + RR < r_end) {
+          float t[24], q[24];
+          resident(rrc, t);
+          tone_row(unit_c, ca0_c, t, q);
+          finish_row(rrc, q);
+        }
+#ifndef MI_MEGA_NOPREFETCH
+        // the next frame's first rows are asked for while the last rows of this one are mapped and stored (unconditional -
+        // the last frame asks for its own rows once more: a condition would keep the OLD contents of these 32 registers
+        // alive from phase A to here, as the other arm of the merge)
+        if constexpr (REGS_FIRST && RR == (MI_MEGA_PREFETCH_AT < NL - 1 ? MI_MEGA_PREFETCH_AT : NL - 1))
+          first_loads(G, mb.io[f + 1 < mb.n_frames ? f + 1 : f].src);
+#endif
+      });
+    });
+  };
+  auto reg_rows = [&]() {
+    static_for<NL, ROWS>([&](auto rrc) {
       constexpr int RR = decltype(rrc)::value;
       if (r_begin + RR < r_end) {
-        float t[24], q[24];
-        resident(rrc, t);
-        tone_row(unit_c, ca0_c, t, q);
+        float q[24];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) q[j] = qr_[RR - NL][j];
         finish_row(rrc, q);
       }
+#ifndef MI_MEGA_NOPREFETCH
+      if constexpr (!REGS_FIRST && RR == (MI_MEGA_PREFETCH_AT_LATE < ROWS - 1 ? MI_MEGA_PREFETCH_AT_LATE : ROWS - 1))
+        first_loads(G, mb.io[f + 1 < mb.n_frames ? f + 1 : f].src);
+#endif
     });
-  });
-  static_for<NL, ROWS>([&](auto rrc) {
+  };
+  static_for<0, PRE2>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
-    if (r_begin + RR < r_end) {
-      float q[24];
-#pragma unroll
-      for (int j = 0; j < 24; ++j) q[j] = qr_[RR - NL][j];
-      finish_row(rrc, q);
-    }
+    if (r_begin + RR < r_end) finish_row(rrc, qpre[RR]);
   });
+  if constexpr (REGS_FIRST) {
+    reg_rows();
+    lds_rows();
+  } else {
+    lds_rows();
+    reg_rows();
+  }
 
-  MI_SSTAMP(8);
+  MI_MSTAMP(8);
   // the launch count of the workspace: every block read it at entry and has passed all barriers before block 0 gets here
-  if (blockIdx.x == 0 && threadIdx.x == 0) m.fpw[FP_EPOCH] = epoch + 1u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(ws)[FP_EPOCH] = epoch + 1u;
+  }   // frames
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -671,16 +882,28 @@ static inline bool geometry(int H, int W, int n_cus, SArgs& a) {
   return a.n_blocks <= 2 * n_cus && (size_t)a.n_blocks * REC <= (size_t)8 * 4096 * sizeof(float);
 }
 
-int launch_rggb(const MArgs& m, hipStream_t stream);
-int launch_grbg(const MArgs& m, hipStream_t stream);
-int launch_gbrg(const MArgs& m, hipStream_t stream);
-int launch_bggr(const MArgs& m, hipStream_t stream);
-static inline int launch(const MArgs& m, int pattern, hipStream_t stream) {
+int launch_rggb(const MBatch& mb, hipStream_t stream);
+int launch_grbg(const MBatch& mb, hipStream_t stream);
+int launch_gbrg(const MBatch& mb, hipStream_t stream);
+int launch_bggr(const MBatch& mb, hipStream_t stream);
+static inline int launch(const MBatch& mb, int pattern, hipStream_t stream) {
   switch (pattern) {
-    case MI_RGGB: return launch_rggb(m, stream);
-    case MI_GRBG: return launch_grbg(m, stream);
-    case MI_GBRG: return launch_gbrg(m, stream);
-    default: return launch_bggr(m, stream);
+    case MI_RGGB: return launch_rggb(mb, stream);
+    case MI_GRBG: return launch_grbg(mb, stream);
+    case MI_GBRG: return launch_gbrg(mb, stream);
+    default: return launch_bggr(mb, stream);
+  }
+}
+int blocks_per_cu_rggb();
+int blocks_per_cu_grbg();
+int blocks_per_cu_gbrg();
+int blocks_per_cu_bggr();
+static inline int blocks_per_cu(int pattern) {
+  switch (pattern) {
+    case MI_RGGB: return blocks_per_cu_rggb();
+    case MI_GRBG: return blocks_per_cu_grbg();
+    case MI_GBRG: return blocks_per_cu_gbrg();
+    default: return blocks_per_cu_bggr();
   }
 }
 

@@ -231,6 +231,19 @@ struct Stats2 {
     sgray += ga; sgray += gb;
     if constexpr (RGB) { s0 += a0; s0 += b0; s1 += a1; s1 += b1; s2 += a2; s2 += b2; }
   }
+  // the same from two gray values (the whole-frame kernel takes them straight from the packed f16 pixels)
+  // (min3 / max3 / max as asm: ga and gb come out of inline asm, and for values of unknown origin the compiler quiets
+  // possible signalling NaNs with a v_max x, x before every min / max - 1.5 instructions per pixel for nothing)
+  MI_DEV void add2_gray(float ga, float gb) {
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(gmin) : "v"(ga), "v"(gb));
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(gmax) : "v"(ga), "v"(gb));
+    float ca, cb;
+    asm("v_max_f32 %0, 0x38d1b717, %1" : "=v"(ca) : "v"(ga));          // max(gray, 1e-4)
+    asm("v_max_f32 %0, 0x38d1b717, %1" : "=v"(cb) : "v"(gb));
+    slog += hw_log2(ca);
+    slog += hw_log2(cb);
+    sgray += ga; sgray += gb;
+  }
   MI_DEV void finish() { gmin = fmaxf(gmin, 1e-4f); gmax = fmaxf(gmax, 1e-4f); }
 };
 #pragma clang fp contract(off)

@@ -26,36 +26,90 @@ def _check_packed(packed):
     return H, W
 
 
+class WholeFrameTimeout(RuntimeError):
+    """A grid barrier of the whole-frame kernel timed out (something else held compute units: a foreign kernel, another
+    process on the GPU).  `.frames`: indices of the frames that were lost and re-issued through the multi-pass chain
+    (empty when the fault was noticed through the device's mailbox only and the frames cannot be told any more)."""
+
+    def __init__(self, msg, frames=()):
+        super().__init__(msg)
+        self.frames = tuple(frames)
+
+
 def whole_frame_fits(H, W, dtype=types.f16):
     """Can pipeline12_reinhard(..., whole_frame=True) take an H x W frame with this output dtype?"""
     return bool(_native.lib().mi_isp_pipeline12_whole_frame_fits(int(H), int(W), types.as_dtype(dtype).code))
 
 
+def _auto_whole_frame(H, W, work, odt, ids_format):
+    return (work.code == types.f16.code and odt.code in (types.u8.code, types.u16.code, types.f16.code)
+            and not ids_format and W % 8 == 0 and whole_frame_fits(H, W, odt))
+
+
+def _failed_frames(ws, n_frames, H, W, device):
+    """Synchronise the current stream and read (and clear) the fault words of n_frames consecutive workspaces."""
+    failed = (_native.c_int * n_frames)()
+    n_bad = _native.c_int(0)
+    _native.check(_native.lib().mi_isp_workspace_check(ws.data_ptr(), n_frames, H, W, failed, _native.ctypes.byref(n_bad),
+                                                       _native.stream_ptr(device)))
+    return [i for i in range(n_frames) if failed[i]]
+
+
+def _report(frames_lost, on_timeout, what):
+    msg = (f"{what}: a grid barrier of the whole-frame kernel timed out for frame(s) {list(frames_lost)} - something else "
+           "held compute units of this GPU; the frames were re-issued through the multi-pass chain and are valid now")
+    if on_timeout == "raise":
+        raise WholeFrameTimeout(msg, frames_lost)
+    import warnings
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def pipeline12_reinhard(packed, pattern=BayerPattern.RGGB, ids_format=False, correct_colors=None,
                         work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0, light_adapt=1.0,
-                        color_adapt=0.0, out=None, whole_frame=False):
-    """whole_frame=True: the single-launch kernel (csrc/isp_mega.h; f16 work dtype, u8 / u16 / f16 output, frames up
-    to 4096 x 3072 on MI355X) instead of the multi-pass chain; same results within the tonemap tolerance."""
+                        color_adapt=0.0, out=None, whole_frame=None, check=None, on_timeout="fallback"):
+    """decode12 -> bayer_to_rgb -> tonemap_reinhard of one packed frame (test/pipeline.py:26-32 of the reference).
+
+    whole_frame: True = the single-launch kernel (csrc/isp_mega.h; f16 work dtype, u8 / u16 / f16 output, frames up to
+    4096 x 3072 on MI355X), False = the multi-pass chain, None (default) = the single-launch kernel whenever it takes the
+    frame.  Same results within the tonemap tolerance.  The single-launch kernel needs the GPU to itself: when a foreign
+    kernel keeps its blocks from being resident together its barriers time out and the frame is invalid.
+    check: True = synchronise, read the frame's fault word and, if it is set, re-issue the frame through the multi-pass
+    chain (the result is then always valid; on_timeout="fallback" warns, "raise" raises WholeFrameTimeout after the
+    re-issue); False = no synchronisation (BatchPipeline.check, or mi_isp_whole_frame_faults, tell later).  Default:
+    True when the kernel was chosen automatically, False when whole_frame=True was asked for."""
     H, W = _check_packed(packed)
     work, odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
     if out is None:
         out = torch.empty((H, W, 3), dtype=odt.torch, device=packed.device)
     ws = _native.workspace(H, W, packed.device)
+    if check is None:
+        check = whole_frame is None
+    if whole_frame is None:
+        whole_frame = _auto_whole_frame(H, W, work, odt, ids_format)
+
+    def multi_pass():
+        # an output dtype other than the work dtype: scratch for the work-dtype image between the passes (the
+        # caching allocator makes this cheap; without it the library re-derives the image in every pass)
+        work_image = None if odt.code == work.code else torch.empty((H, W, 3), dtype=work.torch, device=packed.device)
+        _native.check(_native.lib().mi_isp_pipeline12_reinhard(
+            packed.data_ptr(), out.data_ptr(), None if work_image is None else work_image.data_ptr(),
+            H, W, int(bool(ids_format)), pattern.value, _native.ccm_arg(correct_colors),
+            work.code, odt.code, float(gamma), float(intensity), float(light_adapt), float(color_adapt), ws.data_ptr(),
+            _native.stream_ptr(packed.device)))
+
     if whole_frame:
         assert work.code == types.f16.code, "the whole-frame kernel works in f16"
         _native.check(_native.lib().mi_isp_pipeline12_reinhard_whole_frame(
             packed.data_ptr(), out.data_ptr(), H, W, int(bool(ids_format)), pattern.value,
             _native.ccm_arg(correct_colors), odt.code, float(gamma), float(intensity), float(light_adapt),
             float(color_adapt), ws.data_ptr(), _native.stream_ptr(packed.device)))
+        if check and _failed_frames(ws, 1, H, W, packed.device):
+            with torch.cuda.device(packed.device):
+                _native.lib().mi_isp_whole_frame_faults(1)
+            multi_pass()
+            _report([0], on_timeout, "pipeline12_reinhard")
         return out
-    # an output dtype other than the work dtype: scratch for the work-dtype image between the passes (the
-    # caching allocator makes this cheap; without it the library re-derives the image in every pass)
-    work_image = None if odt.code == work.code else torch.empty((H, W, 3), dtype=work.torch, device=packed.device)
-    _native.check(_native.lib().mi_isp_pipeline12_reinhard(
-        packed.data_ptr(), out.data_ptr(), None if work_image is None else work_image.data_ptr(),
-        H, W, int(bool(ids_format)), pattern.value, _native.ccm_arg(correct_colors),
-        work.code, odt.code, float(gamma), float(intensity), float(light_adapt), float(color_adapt), ws.data_ptr(),
-        _native.stream_ptr(packed.device)))
+    multi_pass()
     return out
 
 
@@ -67,12 +121,17 @@ class BatchPipeline:
 
     def __init__(self, n_frames, H, W, device, n_streams=2, pattern=BayerPattern.RGGB, ids_format=False,
                  correct_colors=None, work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0,
-                 light_adapt=1.0, color_adapt=0.0, use_graph=False, whole_frame=False):
+                 light_adapt=1.0, color_adapt=0.0, use_graph=False, whole_frame=None, on_timeout="fallback"):
         self.n_frames, self.H, self.W, self.device = n_frames, H, W, device
-        self.whole_frame = bool(whole_frame)          # every frame through the single-launch kernel (csrc/isp_mega.h)
+        self.work, self.odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
+        if whole_frame is None:                       # the single-launch kernel whenever it takes these frames
+            with torch.cuda.device(device):
+                whole_frame = _auto_whole_frame(H, W, self.work, self.odt, ids_format)
+        self.whole_frame = bool(whole_frame)          # the batch through ONE launch of the whole-frame kernel (csrc/isp_mega.h)
+        self.on_timeout = on_timeout
+        self._last_frames = None
         if self.whole_frame:
             n_streams = 1                             # two whole-frame grids must never share the chip
-        self.work, self.odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
         self.pattern, self.ids = pattern, int(bool(ids_format))
         self.ccm = _native.ccm_arg(correct_colors)
         self.params = (float(gamma), float(intensity), float(light_adapt), float(color_adapt))
@@ -102,9 +161,17 @@ class BatchPipeline:
                 pass
 
     def __call__(self, frames, eager=False):
+        """Issue the batch (asynchronously).  With the whole-frame kernel: if the device's fault mailbox says that an
+        earlier launch timed out, the previous batch is checked and repaired first (see check())."""
         assert len(frames) == self.n_frames
         for f in frames:
             assert _check_packed(f) == (self.H, self.W)
+        if self.whole_frame:
+            with torch.cuda.device(self.device):
+                pending = _native.lib().mi_isp_whole_frame_faults(0)
+            if pending and self._last_frames is not None:
+                self.check()
+            self._last_frames = list(frames)
         if self.use_graph and not eager:
             key = tuple(f.data_ptr() for f in frames)
             if self._graph is None or key != self._graph_key:
@@ -124,6 +191,30 @@ class BatchPipeline:
             _native.check(_native.lib().mi_isp_pipeline12_graph_launch(self._graph, _native.stream_ptr(self.device)))
             return self.outputs
         return self._issue(frames)
+
+    def check(self, frames=None):
+        """Synchronise and make sure every output of the last batch is valid: frames whose fault word is set (a barrier
+        of the whole-frame kernel timed out) are re-issued through the multi-pass chain; returns their indices
+        (on_timeout="raise": raises WholeFrameTimeout after the repair).  No-op for the multi-pass chain."""
+        frames = self._last_frames if frames is None else frames
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            if not self.whole_frame:
+                return []
+            lost = _failed_frames(self.ws, self.n_frames, self.H, self.W, self.device)
+            _native.lib().mi_isp_whole_frame_faults(1)
+            if lost:
+                assert frames is not None, "check(): pass the frames of the batch that was lost"
+                g, i, la, ca = self.params
+                ws_bytes = int(_native.lib().mi_isp_workspace_bytes(self.H, self.W))
+                for k in lost:
+                    _native.check(_native.lib().mi_isp_pipeline12_reinhard(
+                        frames[k].data_ptr(), self.outputs[k].data_ptr(), None, self.H, self.W, self.ids, self.pattern.value,
+                        self.ccm, self.work.code, self.odt.code, g, i, la, ca, self.ws.data_ptr() + k * ws_bytes,
+                        _native.stream_ptr(self.device)))
+                torch.cuda.synchronize(self.device)
+                _report(lost, self.on_timeout, "BatchPipeline")
+        return lost
 
     def prepare(self, frames):
         """Set-up outside any timed region: library warm-up and (use_graph) the capture for these buffers."""
@@ -145,12 +236,10 @@ class BatchPipeline:
         in_ptrs = _native.ptr_array(frames)
         g, i, la, ca = self.params
         if self.whole_frame:
-            ws_bytes = int(_native.lib().mi_isp_workspace_bytes(self.H, self.W))
-            with torch.cuda.stream(self.streams[0]):
-                for k, f in enumerate(frames):
-                    _native.check(_native.lib().mi_isp_pipeline12_reinhard_whole_frame(
-                        f.data_ptr(), self.outputs[k].data_ptr(), self.H, self.W, self.ids, self.pattern.value, self.ccm,
-                        self.odt.code, g, i, la, ca, self.ws.data_ptr() + k * ws_bytes, self.streams[0].cuda_stream))
+            # one launch for the whole batch: the resident grid walks through the frames (csrc/isp_mega.h)
+            _native.check(_native.lib().mi_isp_pipeline12_reinhard_whole_frame_batch(
+                in_ptrs, self.out_ptrs, self.n_frames, self.H, self.W, self.ids, self.pattern.value, self.ccm,
+                self.odt.code, g, i, la, ca, self.ws.data_ptr(), self.streams[0].cuda_stream))
             cur.wait_stream(self.streams[0])
             return self.outputs
         _native.check(_native.lib().mi_isp_pipeline12_reinhard_batch(

@@ -141,7 +141,7 @@ def test_pipeline12_4k_non_unit_bounds(ti, dev, scenes, out):
     cfa = c_oracle.decode12_scaled(packed, work="f16").reshape(3072, 4096)
     rgb = c_oracle.demosaic(cfa, 0, round_f16=True)
     assert rgb.min() > 0.0 and rgb.max() < 1.0, "the frame must not touch the clamp"
-    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=getattr(ti.types, out)).cpu().numpy()
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=getattr(ti.types, out), whole_frame=False).cpu().numpy()
     assert_close(got, ref, f"pipeline12 4K non-unit bounds -> {out}")
 
 
@@ -257,6 +257,104 @@ def test_whole_frame_kernel_refuses_what_it_cannot_hold(ti, dev):
     big = torch.zeros((3084, 6144), dtype=torch.uint8, device=dev)
     with pytest.raises(RuntimeError, match="whole-frame"):
         pipeline12_reinhard(big, whole_frame=True)
+
+
+def test_whole_frame_batch_launch_equals_single_launches(ti, dev, rng, scenes):
+    """One launch walks through a batch (mi_isp_pipeline12_reinhard_whole_frame_batch): unit and non-unit frames mixed,
+    more frames than one launch takes (64), every output bit-identical to a launch of its own and within tolerance of the
+    C oracle; a small geometry with partial row bands too."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard, BatchPipeline
+    packed = [packed_from(scenes[0]), packed_from(scenes[1], 0.7, 0.1), packed_from(scenes[2])]
+    frames = [torch.from_numpy(p).to(dev) for p in packed]
+    singles = [pipeline12_reinhard(f, whole_frame=True).clone() for f in frames]
+    bp = BatchPipeline(5, 3072, 4096, dev, whole_frame=True)
+    order = [0, 1, 2, 1, 0]
+    outs = bp([frames[k] for k in order])
+    assert bp.check() == []
+    for i, k in enumerate(order):
+        assert torch.equal(outs[i], singles[k]), f"batch frame {i} differs from its single launch"
+    for k in range(2):
+        assert_close(singles[k].cpu().numpy(), c_oracle.pipeline12_reinhard(packed[k], work="f16", out="f16"), f"frame {k}")
+    # 70 small frames = two launches (64 + 6); 130 rows: the last band of every column of waves is partial
+    small = [natural_packed12(np.random.default_rng(100 + k), 130, 1544) for k in range(3)]
+    sm = [torch.from_numpy(p).to(dev) for p in small]
+    ref = [pipeline12_reinhard(f, whole_frame=True).clone() for f in sm]
+    bp = BatchPipeline(70, 130, 1544, dev, whole_frame=True, dtype=ti.types.u8, gamma=0.7)
+    ref8 = [pipeline12_reinhard(f, whole_frame=True, dtype=ti.types.u8, gamma=0.7).clone() for f in sm]
+    outs = bp([sm[i % 3] for i in range(70)])
+    assert bp.check() == []
+    for i in range(70):
+        assert torch.equal(outs[i], ref8[i % 3]), f"small batch frame {i}"
+    assert_close(ref[0].cpu().numpy(), c_oracle.pipeline12_reinhard(small[0], work="f16", out="f16"), "small frame")
+
+
+def test_default_chain_is_the_whole_frame_kernel_when_it_fits(ti, dev, rng):
+    """pipeline12_reinhard / BatchPipeline pick the single-launch kernel by themselves for frames it takes (and check its
+    fault word), the multi-pass chain for the others."""
+    from taichi_image_amd.pipeline import pipeline12_reinhard, BatchPipeline, whole_frame_fits
+    packed = natural_packed12(rng, 96, 1024)
+    f = torch.from_numpy(packed).to(dev)
+    assert torch.equal(pipeline12_reinhard(f), pipeline12_reinhard(f, whole_frame=True))
+    assert BatchPipeline(2, 96, 1024, dev).whole_frame
+    # f32 work dtype, f32 output, the IDS layout: not the whole-frame kernel's - the multi-pass chain, same call
+    assert not BatchPipeline(2, 96, 1024, dev, dtype=ti.types.f32).whole_frame
+    got = pipeline12_reinhard(f, work_dtype=ti.types.f32, dtype=ti.types.f32)
+    assert_close(got.cpu().numpy(), O.pipeline12_reinhard(packed, 0, False, None, "f32", "f32"), "auto -> multi-pass f32")
+    ids = natural_packed12(rng, 96, 1024, ids_format=True)
+    got = pipeline12_reinhard(torch.from_numpy(ids).to(dev), ids_format=True)
+    assert_close(got.cpu().numpy(), O.pipeline12_reinhard(ids, 0, True), "auto -> multi-pass ids")
+    assert not whole_frame_fits(3084, 4096)
+    big = natural_packed12(rng, 3084, 4096)
+    got = pipeline12_reinhard(torch.from_numpy(big).to(dev))
+    assert_close(got.cpu().numpy(), c_oracle.pipeline12_reinhard(big, work="f16", out="f16"), "auto -> multi-pass big")
+
+
+def test_whole_frame_timeout_is_reported_and_repaired(ti, dev, scenes):
+    """A barrier that times out (provoked with a poll budget of one round) must not pass silently: the fault word of the
+    frame and the device's mailbox are set, the checked call re-issues the frame through the multi-pass chain - the output
+    then equals the oracle - and warns or raises; BatchPipeline.check() repairs a batch the same way."""
+    from taichi_image_amd import _native
+    from taichi_image_amd.pipeline import pipeline12_reinhard, BatchPipeline, WholeFrameTimeout
+    L = _native.lib()
+    packed = [packed_from(scenes[0]), packed_from(scenes[1], 0.7, 0.1)]
+    frames = [torch.from_numpy(p).to(dev) for p in packed]
+    refs = [c_oracle.pipeline12_reinhard(p, work="f16", out="f16") for p in packed]
+    good = pipeline12_reinhard(frames[0], whole_frame=True).clone()
+    torch.cuda.synchronize()
+    assert L.mi_isp_whole_frame_faults(1) == 0
+    L.mi_isp_whole_frame_set_poll_limit(1)
+    try:
+        out = torch.zeros_like(good)
+        with pytest.raises(WholeFrameTimeout) as ei:
+            pipeline12_reinhard(frames[0], out=out, whole_frame=True, check=True, on_timeout="raise")
+        assert ei.value.frames == (0,)
+        assert_close(out.cpu().numpy(), refs[0], "re-issued frame (raise)")
+        with pytest.warns(RuntimeWarning, match="timed out"):
+            got = pipeline12_reinhard(frames[1])                  # the default: auto-selected, checked, repaired
+        assert_close(got.cpu().numpy(), refs[1], "re-issued frame (default)")
+        # unchecked: the call returns, the mailbox tells without a synchronisation of the caller's
+        pipeline12_reinhard(frames[0], out=out, whole_frame=True)
+        torch.cuda.synchronize()
+        assert L.mi_isp_whole_frame_faults(0) != 0 and _error_word(ti, 3072, 4096, dev) != 0
+        assert _native.workspace(3072, 4096, dev) is not None
+        bp = BatchPipeline(3, 3072, 4096, dev, whole_frame=True)
+        outs = bp([frames[0], frames[1], frames[0]])
+        with pytest.warns(RuntimeWarning, match="timed out"):
+            lost = bp.check()
+        assert len(lost) >= 1
+        for o, k in zip(outs, (0, 1, 0)):
+            assert_close(o.cpu().numpy(), refs[k], "repaired batch frame")
+    finally:
+        L.mi_isp_whole_frame_set_poll_limit(0)
+        torch.cuda.synchronize()
+        L.mi_isp_whole_frame_faults(1)
+        # the fault word of the shared workspace is sticky: clear it for the tests that follow
+        ws = _native.workspace(3072, 4096, dev)
+        off = int(L.mi_isp_workspace_error_offset(3072, 4096))
+        ws[off:off + 4].zero_()
+    again = pipeline12_reinhard(frames[0], whole_frame=True)
+    torch.cuda.synchronize()
+    assert _error_word(ti, 3072, 4096, dev) == 0 and torch.equal(again, good)
 
 
 # ---- boundary: one C call per camera group (mi_isp_camera_frame_batch), straight through ctypes ------------------

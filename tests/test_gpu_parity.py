@@ -281,7 +281,7 @@ def test_pipeline12_reinhard(ti, rng, dev, p, ids, work, dout, shape):
     from taichi_image_amd.pipeline import pipeline12_reinhard
     packed = natural_packed12(rng, *shape, pattern=p, ids_format=ids)
     got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), pat(ti, p), ids, work_dtype=tok(ti, work),
-                              dtype=tok(ti, dout)).cpu().numpy()
+                              dtype=tok(ti, dout), whole_frame=False).cpu().numpy()
     ref = O.pipeline12_reinhard(packed, p, ids, None, work, dout)
     assert_close(got, ref, f"pipeline12 {shape} p{p} {work}->{dout}")
 
@@ -308,7 +308,7 @@ def test_pipeline12_params_and_ccm(ti, rng, dev):
     packed = natural_packed12(rng, 96, 160)
     ccm = O.isp_color_matrix(True, O.DEFAULT_WB, O.DEFAULT_CC)
     kw = dict(gamma=0.6, intensity=1.5, light_adapt=0.7, color_adapt=0.4)
-    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), correct_colors=ccm, **kw).cpu().numpy()
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), correct_colors=ccm, **kw, whole_frame=False).cpu().numpy()
     ref = O.pipeline12_reinhard(packed, correct_colors=ccm, **kw)
     assert_close(got, ref, "pipeline12 ccm+params")
 
@@ -326,7 +326,7 @@ def test_specialised_kernels_random_shapes(ti, dev):
         p = int(r.integers(0, 4)); ids = bool(r.integers(0, 2)); use_ccm = trial % 3 == 0
         packed = natural_packed12(r, H, W, pattern=p, ids_format=ids)
         cc = ccm if use_ccm else None
-        got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), pat(ti, p), ids, correct_colors=cc).cpu().numpy()
+        got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), pat(ti, p), ids, correct_colors=cc, whole_frame=False).cpu().numpy()
         assert_close(got, O.pipeline12_reinhard(packed, p, ids, cc), f"pipeline12 {H}x{W} p{p} ids={ids} ccm={use_ccm}")
         # demosaic alone: bit-exact, f16 CFA and u16 CFA
         cfa = random_cfa(r, H, W, "f16")
@@ -343,7 +343,7 @@ def test_pipeline12_matches_unfused_chain_4k(ti, dev):
     from taichi_image_amd.synthetic import synthetic_packed12
     packed = synthetic_packed12(0)
     pk = torch.from_numpy(packed).to(dev)
-    fused = pipeline12_reinhard(pk)
+    fused = pipeline12_reinhard(pk, whole_frame=False)
     cfa = ti.packed.decode12(pk, ti.types.f16, scaled=True)
     rgb = ti.bayer.bayer_to_rgb(cfa)
     unfused = ti.tonemap.tonemap_reinhard(rgb, dtype=ti.types.f16)
@@ -364,12 +364,12 @@ def test_pipeline12_50mp_matches_unfused_chain(ti, dev):
     small = synthetic_packed12(2, 1536, 2048)
     packed = np.tile(small, (4, 4))                        # periodic 50 MP frame, cheap to build
     pk = torch.from_numpy(packed).to(dev)
-    fused = pipeline12_reinhard(pk)
+    fused = pipeline12_reinhard(pk, whole_frame=False)
     rgb = ti.bayer.bayer_to_rgb(ti.packed.decode12(pk, ti.types.f16, scaled=True))
     unfused = ti.tonemap.tonemap_reinhard(rgb, dtype=ti.types.f16)
     assert fused.shape == (6144, 8192, 3)
     assert torch.equal(fused, unfused)
-    fused8 = pipeline12_reinhard(pk, dtype=ti.types.u8, gamma=0.6)
+    fused8 = pipeline12_reinhard(pk, dtype=ti.types.u8, gamma=0.6, whole_frame=False)
     unfused8 = ti.tonemap.tonemap_reinhard(rgb, gamma=0.6, dtype=ti.types.u8)
     diff = (fused8.int() - unfused8.int()).abs()
     assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
@@ -383,9 +383,9 @@ def test_pipeline12_4k_against_c_oracle(ti, dev):
     from taichi_image_amd.pipeline import pipeline12_reinhard
     from taichi_image_amd.synthetic import synthetic_packed12
     packed = synthetic_packed12(3)
-    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev)).cpu().numpy()
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), whole_frame=False).cpu().numpy()
     assert_close(got, c_oracle.pipeline12_reinhard(packed), "pipeline12 4K vs C oracle")
-    got8 = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=ti.types.u8, gamma=0.6).cpu().numpy()
+    got8 = pipeline12_reinhard(torch.from_numpy(packed).to(dev), dtype=ti.types.u8, gamma=0.6, whole_frame=False).cpu().numpy()
     assert_close(got8, c_oracle.pipeline12_reinhard(packed, out="u8", gamma=0.6), "pipeline12 4K u8 vs C oracle")
 
 
@@ -398,7 +398,7 @@ def test_pipeline12_5mp_sensor_against_c_oracle(ti, dev):
     from taichi_image_amd.pipeline import pipeline12_reinhard
     from taichi_image_amd.synthetic import synthetic_packed12
     packed = synthetic_packed12(5, 2050, 2448)
-    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev)).cpu().numpy()
+    got = pipeline12_reinhard(torch.from_numpy(packed).to(dev), whole_frame=False).cpu().numpy()
     assert_close(got, c_oracle.pipeline12_reinhard(packed), "pipeline12 2448x2050 vs C oracle")
 
 
@@ -406,11 +406,11 @@ def test_batch_pipeline_equals_single(ti, rng, dev):
     from taichi_image_amd.pipeline import BatchPipeline, pipeline12_reinhard
     H, W = 64, 128
     frames = [torch.from_numpy(natural_packed12(rng, H, W)).to(dev) for _ in range(5)]
-    bp = BatchPipeline(5, H, W, dev, n_streams=3)
+    bp = BatchPipeline(5, H, W, dev, n_streams=3, whole_frame=False)
     outs = [o.clone() for o in bp(frames)]
     torch.cuda.synchronize()
     for f, o in zip(frames, outs):
-        assert torch.equal(o, pipeline12_reinhard(f))
+        assert torch.equal(o, pipeline12_reinhard(f, whole_frame=False))
 
 
 def test_batch_pipeline_graph_replay(ti, rng, dev):
@@ -420,19 +420,19 @@ def test_batch_pipeline_graph_replay(ti, rng, dev):
     H, W = 64, 128
     host = [natural_packed12(rng, H, W) for _ in range(8)]
     bufs = [torch.from_numpy(host[i]).to(dev) for i in range(4)]
-    bp = BatchPipeline(4, H, W, dev, n_streams=2, use_graph=True)
+    bp = BatchPipeline(4, H, W, dev, n_streams=2, use_graph=True, whole_frame=False)
     for round_ in range(3):
         for i in range(4):
             bufs[i].copy_(torch.from_numpy(host[(i + round_) % 8]))       # same addresses, new frames
         outs = [o.clone() for o in bp(bufs, eager=(round_ == 1))]
         torch.cuda.synchronize()
         for i, o in enumerate(outs):
-            assert torch.equal(o, pipeline12_reinhard(torch.from_numpy(host[(i + round_) % 8]).to(dev)))
+            assert torch.equal(o, pipeline12_reinhard(torch.from_numpy(host[(i + round_) % 8]).to(dev), whole_frame=False))
     other = [torch.from_numpy(host[4 + i]).to(dev) for i in range(4)]         # different buffers: recapture
     outs = [o.clone() for o in bp(other)]
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
-        assert torch.equal(o, pipeline12_reinhard(other[i]))
+        assert torch.equal(o, pipeline12_reinhard(other[i], whole_frame=False))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -638,11 +638,11 @@ def test_upload_ring_pipeline_matches_direct(dev):
     outs = []
     for f in frames:                                   # more frames than slots: slots are reused
         slot, dev_bytes = ring.upload(f)
-        outs.append(pipeline12_reinhard(dev_bytes.view(H, W * 3 // 2)))
+        outs.append(pipeline12_reinhard(dev_bytes.view(H, W * 3 // 2), whole_frame=False))
         slot.release()
     torch.cuda.synchronize()
     for f, o in zip(frames, outs):
-        want = pipeline12_reinhard(torch.from_numpy(f).to(dev))
+        want = pipeline12_reinhard(torch.from_numpy(f).to(dev), whole_frame=False)
         assert_exact(o.cpu().numpy(), want.cpu().numpy(), "ring-fed frame")
 
 
