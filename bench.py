@@ -236,7 +236,7 @@ def other_workloads(frames, host, device, frames_per_step):
     for odt, nbytes, tag in ((types.f16, 31315968, "f16"), (types.u8, 25095168, "u8")):
         def step3b():
             for f in frames[:4]:
-                interpolate.resize_bilinear(isp_full.load_packed12(f), scale=(0.3515625, 0.46875), dtype=odt)
+                interpolate.resize_bilinear(isp_full.load_packed12(f), (1920, 1080), scale=(0.3515625, 0.46875), dtype=odt)
         runs = [timed(step3b, 50, 3, device) / (50 * 4) * 1e6 for _ in range(3)]
         entry(f"config3b_resize_1920x1080_{tag}", runs, nbytes, 4, 50,
               note="load_packed12 (full-size f16 RGB materialised, as the reference does) + resize_bilinear with the per-axis scale")
@@ -313,7 +313,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if not torch.cuda.is_available():
+        print(f"bench.py rank {rank}/{world}: needs a GPU (there is no CPU fallback)", file=sys.stderr, flush=True)
+        sys.exit(3)
     # MI_ISP_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than
     # ranks (ranks share devices, timing tensors go through the host); the real runs use RCCL
     backend = os.environ.get("MI_ISP_BENCH_BACKEND", "nccl")

@@ -173,6 +173,7 @@ static struct {
   size_t used = 0;
   int every = 1;                  // every n-th frame is sampled (events between launches cost gaps)
   long frames_seen = 0;
+  std::vector<int> npass;         // passes recorded per sampled frame (4; 1 for a whole-frame launch)
 } g_prof;
 
 extern "C" int mi_isp_profile_enable(int max_frames, int every) {
@@ -183,6 +184,7 @@ extern "C" int mi_isp_profile_enable(int max_frames, int every) {
   g_prof.on = max_frames > 0;
   g_prof.every = every > 0 ? every : 1;
   g_prof.frames_seen = 0;
+  g_prof.npass.assign(max_frames > 0 ? max_frames : 0, 4);
   for (int i = 0; i < 8 * max_frames; ++i) {
     hipEvent_t e;
     MI_HIP(hipEventCreate(&e));
@@ -197,7 +199,7 @@ extern "C" int mi_isp_profile_collect(float avg_us[4], int* count) {
   double sum[4] = {0, 0, 0, 0};
   int n = 0;
   for (size_t f = 0; f + 8 <= g_prof.used; f += 8, ++n) {
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < g_prof.npass[f / 8]; ++k) {
       float ms = 0.f;
       MI_HIP(hipEventSynchronize(g_prof.ev[f + 2 * k + 1]));
       MI_HIP(hipEventElapsedTime(&ms, g_prof.ev[f + 2 * k], g_prof.ev[f + 2 * k + 1]));
@@ -216,14 +218,14 @@ struct PassTimer {
   int begin(int k) const { if (on) MI_HIP(hipEventRecord(g_prof.ev[base + 2 * k], s)); return 0; }
   int end(int k) const { if (on) MI_HIP(hipEventRecord(g_prof.ev[base + 2 * k + 1], s)); return 0; }
 };
-static PassTimer pass_timer(hipStream_t s) {
+static PassTimer pass_timer(hipStream_t s, int npass = 4) {
   std::lock_guard<std::mutex> lock(g_prof.mu);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (g_prof.on) (void)hipStreamIsCapturing(s, &cap);
   if (cap != hipStreamCaptureStatusNone) return PassTimer{0, false, s};   // events inside a graph cannot be timed
   const bool sampled = g_prof.on && (g_prof.frames_seen++ % g_prof.every) == 0;
   PassTimer t = {g_prof.used, sampled && g_prof.used + 8 <= g_prof.ev.size(), s};
-  if (t.on) g_prof.used += 8;
+  if (t.on) { g_prof.npass[g_prof.used / 8] = npass; g_prof.used += 8; }
   return t;
 }
 
@@ -381,7 +383,7 @@ static int mega_launch_frames(tile::Params p, strm::SArgs a, int pattern, float 
 #endif
   const bool direct = cap == hipStreamCaptureStatusNone;
   if (direct && g_mega.has_last[dev] && g_mega.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, g_mega.done[dev], 0));
-  const PassTimer tm = direct ? pass_timer(s) : PassTimer{0, false, s};   // measurement aid: a launch as "pass 0"
+  const PassTimer tm0 = direct ? pass_timer(s, 1) : PassTimer{0, false, s};   // measurement aid: a launch as "pass 0"
   for (int i0 = 0; i0 < n; i0 += mega::MAX_BATCH) {
     mb.n_frames = n - i0 < mega::MAX_BATCH ? n - i0 : mega::MAX_BATCH;
     for (int i = 0; i < mb.n_frames; ++i) {
@@ -389,13 +391,11 @@ static int mega_launch_frames(tile::Params p, strm::SArgs a, int pattern, float 
       mb.io[i].dst = dsts[i0 + i];
       mb.io[i].ws = ws + (size_t)(i0 + i) * ws_floats;
     }
+    // (events around the first launch of the call only: a call of more than 64 frames is several launches)
+    const PassTimer tm = i0 == 0 ? tm0 : PassTimer{0, false, s};
     if (int rc = tm.begin(0)) return rc;
     if (int rc = mega::launch(mb, pattern, s)) return rc;
     if (int rc = tm.end(0)) return rc;
-    for (int k = 1; k < 4; ++k) {                            // the other three slots of the sampled launch: zero-length
-      if (int rc = tm.begin(k)) return rc;
-      if (int rc = tm.end(k)) return rc;
-    }
   }
   if (direct) {
     if (!g_mega.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_mega.done[dev], hipEventDisableTiming));

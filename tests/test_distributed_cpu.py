@@ -100,3 +100,26 @@ def test_single_process_passthrough():
     assert not D.active(None) and D.world_size(None) == 1
     g = D.all_gather_rows(raw, None)
     assert g.shape == (1, 2) and torch.equal(g[0], raw)
+
+
+@pytest.mark.timeout(300)
+def test_bench_spawns_its_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent - before anything touches a GPU - starts two rank
+    processes with RANK / WORLD_SIZE / MASTER_* set and returns the worst exit code.  On this GPU-less box each rank
+    stops at its "needs a GPU" check (exit code 3), which is the evidence that both were started with the right ranks."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("covered by tests/test_distributed_gpu.py::test_bench_starts_its_own_ranks_on_one_gpu")
+    env = dict(os.environ, MI_ISP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    for rank in (0, 1):
+        assert f"rank {rank}/2" in r.stderr, r.stderr[-1500:]
+    # a launcher's environment is taken as it is (no second spawn): WORLD_SIZE=1 with --gpus 2 is the launcher's error
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

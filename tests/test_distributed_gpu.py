@@ -55,7 +55,7 @@ def _worker(rank, world, port, q):
     mine = lambda step: [_packed(step, k) for k in range(6)][rank::world]
     metrics, outs = _run_isp(mine, dist.group.WORLD, dev)
     # config 4: this rank's share of independent frames through the stateless chain
-    stateless = [pipeline12_reinhard(torch.from_numpy(p).to(dev)).cpu().numpy() for p in mine(0)]
+    stateless = [pipeline12_reinhard(torch.from_numpy(p).to(dev), whole_frame=False).cpu().numpy() for p in mine(0)]   # two processes share this GPU: not the whole-frame kernel
     q.put((rank, metrics, outs, stateless))
     dist.barrier()
     dist.destroy_process_group()
@@ -90,7 +90,24 @@ def test_two_ranks_through_the_hip_kernels():
                 d = np.abs(o.astype(np.int32) - want.astype(np.int32))
                 assert d.max() <= 1 and (d > 0).mean() < 0.01, (step, r, j, d.max())
         assert np.array_equal(got[0][0][step], got[1][0][step])     # identical state on every rank
-    full = [pipeline12_reinhard(torch.from_numpy(_packed(0, k)).to(dev)).cpu().numpy() for k in range(6)]
+    full = [pipeline12_reinhard(torch.from_numpy(_packed(0, k)).to(dev), whole_frame=False).cpu().numpy() for k in range(6)]
     for r in range(world):
         for j, o in enumerate(got[r][2]):
             assert np.array_equal(o.view(np.uint16), full[r + world * j].view(np.uint16)), (r, j)
+
+
+@pytest.mark.timeout(600)
+def test_bench_starts_its_own_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher: the parent spawns two ranks (gloo rehearsal: both on cuda:0, so the
+    multi-pass chain), relays rank 0's line and returns 0."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_ISP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
+    assert "multi-pass" in line["config"]["chain"]
