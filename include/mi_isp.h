@@ -174,6 +174,17 @@ int mi_isp_tonemap_reinhard(const void* src_dev, void* dst_dev, int H, int W, in
 int mi_isp_load_packed(const uint8_t* packed_dev, void* rgb_dev, int H, int W, int bits,
                        int ids_format, int pattern, const float* ccm9_host, int work_dtype,
                        int Hd, int Wd, float scale, void* stream);
+/* The same, and the image's metering subsample on the way: sub_dev receives rgb[::sub_stride, ::sub_stride] as a dense
+ * (ceil(Hd / sub_stride), ceil(Wd / sub_stride), 3) image of work_dtype - what ISP.update_metering reads of every image
+ * (camera_isp.py:168-170).  mi_isp_metering(..) on these buffers with stride 1 gives the bits of mi_isp_metering on the
+ * images with stride sub_stride (same samples, same order) without the strided gather over the full-size images.  With
+ * sub_stride 8 and no resize the subsample is written by the load kernel itself; otherwise by a small gather behind it. */
+int mi_isp_load_packed_metered(const uint8_t* packed_dev, void* rgb_dev, int H, int W, int bits,
+                               int ids_format, int pattern, const float* ccm9_host, int work_dtype,
+                               int Hd, int Wd, float scale, void* sub_dev, int sub_stride, void* stream);
+/* 1 if mi_isp_load_packed_metered (scale <= 0, 16-byte aligned buffers) writes the subsample from inside the load
+ * kernel, 0 if it would need the gather behind it (then the caller may as well let mi_isp_metering gather). */
+int mi_isp_load_packed_metered_is_fused(int H, int W, int bits, int ids_format, int work_dtype, int sub_stride);
 /* 1 if mi_isp_load_packed can fuse a resize by `scale` (its LDS tile holds the source region of a
  * 64x16 destination tile for scale >= ~0.39, any upscale); otherwise demosaic at full size and
  * call mi_isp_resize_bilinear. */

@@ -206,11 +206,27 @@ def camera_isp(name: str, dtype=types.f32):
             fused = scale > 0 and min(out_size) > 0 and L.mi_isp_load_packed_scale_supported(float(scale))
             wd, hd = out_size if fused else (w, h)
             rgb = torch.empty((hd, wd, 3), dtype=torch_dtype, device=self.device)
-            _native.check(L.mi_isp_load_packed(
+            if not fused and scale > 0:                  # a scale the fused kernel does not take: resize separately
+                _native.check(L.mi_isp_load_packed(
+                    src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
+                    _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, 0.0, _native.stream_ptr(self.device)))
+                return self.resize_image(rgb)
+            st = self.metering_stride
+            if fused or not L.mi_isp_load_packed_metered_is_fused(h, w, bits, int(bool(ids_format)), dtype.code, st):
+                _native.check(L.mi_isp_load_packed(
+                    src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
+                    _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, float(scale) if fused else 0.0,
+                    _native.stream_ptr(self.device)))
+                return rgb
+            # the image and, on the way, the stride-subsampled copy update_metering will ask for (camera_isp.py:168-170):
+            # the load kernel holds those pixels anyway, the strided gather over six 4K images costs 25 us per call
+            sub = torch.empty(((hd + st - 1) // st, (wd + st - 1) // st, 3), dtype=torch_dtype, device=self.device)
+            _native.check(L.mi_isp_load_packed_metered(
                 src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
-                _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, float(scale) if fused else 0.0,
-                _native.stream_ptr(self.device)))
-            return rgb if fused else self.resize_image(rgb)
+                _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, 0.0,
+                sub.data_ptr(), st, _native.stream_ptr(self.device)))
+            rgb._mi_metering_sub = (sub, st, rgb._version)    # valid while nobody writes to the image through torch
+            return rgb
 
         def load_packed12(self, image_data, ids_format=False):
             """camera_isp.py:333-340: unpack + demosaic (+ccm) fused in one pass over the packed frame."""
@@ -243,26 +259,34 @@ def camera_isp(name: str, dtype=types.f32):
                 assert im.shape == images[0].shape, "all images of one call must share a shape"
             H, W = images[0].shape[:2]
             ws = _native.workspace(H, W, self.device)
+            stride = self.metering_stride
+            # images that came out of load_packed12 / 16 carry their subsample: the same samples in the same order from a
+            # dense buffer (stride 1) - identical results, no strided gather over the full-size images
+            tags = [getattr(im, "_mi_metering_sub", None) for im in images]
+            if all(t is not None and t[1] == stride and t[2] == im._version for t, im in zip(tags, images)):
+                images = [t[0] for t in tags]
+                H, W = images[0].shape[:2]
+                stride = 1
             ptrs = _native.ptr_array(images)
             L = _native.lib()
             stream = _native.stream_ptr(self.device)
             if self.process_group is None:
                 metering = prev.clone()
-                _native.check(L.mi_isp_metering(ptrs, len(images), H, W, self.metering_stride, dtype.code,
+                _native.check(L.mi_isp_metering(ptrs, len(images), H, W, stride, dtype.code,
                                                 metering.data_ptr(), float(t), ws.data_ptr(), stream))
                 return metering
             # sharded batch: the same two data passes, an all-gather after each (two collectives per call), the ranks'
             # rows combined by one small kernel each on this stream (mi_isp_metering_combine_*)
             world = _dist.world_size(self.process_group)
             raw = torch.empty(2, dtype=torch.float32, device=self.device)
-            _native.check(L.mi_isp_metering_bounds(ptrs, len(images), H, W, self.metering_stride, dtype.code,
+            _native.check(L.mi_isp_metering_bounds(ptrs, len(images), H, W, stride, dtype.code,
                                                    raw.data_ptr(), ws.data_ptr(), stream))
             gathered = _dist.all_gather_rows(raw, self.process_group)
             b = torch.empty(2, dtype=torch.float32, device=self.device)
             _native.check(L.mi_isp_metering_combine_bounds(gathered.data_ptr(), world, prev.data_ptr(), float(t),
                                                            b.data_ptr(), stream))
             part = torch.empty(8, dtype=torch.float32, device=self.device)
-            _native.check(L.mi_isp_metering_sums(ptrs, len(images), H, W, self.metering_stride, dtype.code,
+            _native.check(L.mi_isp_metering_sums(ptrs, len(images), H, W, stride, dtype.code,
                                                  b.data_ptr(), part.data_ptr(), ws.data_ptr(), stream))
             gathered8 = _dist.all_gather_rows(part, self.process_group)
             metering = prev.clone()

@@ -125,9 +125,9 @@ static bool use_stream(const tile::Params& p, int work_dtype, const void* out, i
          (int64_t)p.H * p.W * 3 * (int64_t)mi_dtype_size(out_dtype) < (int64_t)strm::INVALID_OFF;
 }
 
-extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,
-                                  int pattern, const float* ccm9, int work_dtype, int Hd, int Wd, float scale,
-                                  void* stream) {
+static int load_packed_impl(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,
+                            int pattern, const float* ccm9, int work_dtype, int Hd, int Wd, float scale,
+                            void* sub, int sub_stride, void* stream) {
   MI_REQUIRE(rgb, "load_packed: null output");
   tile::Params p = {};
   if (int rc = fill_common(p, H, W, pattern, ccm9, "load_packed")) return rc;
@@ -143,13 +143,17 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
 #ifdef MI_STREAM_STAMPS
       ra.t.partials = stamp_buffer(); ra.t.part_stride = 0;      // this entry point has no workspace: a buffer of the build
 #endif
-      return rstrm::launch(ra, pattern, (hipStream_t)stream);
+      if (int rc = rstrm::launch(ra, pattern, (hipStream_t)stream)) return rc;
+      if (sub) return ew::subsample(rgb, sub, Hd, Wd, sub_stride, work_dtype, (hipStream_t)stream);
+      return 0;
     }
     MI_REQUIRE(rtile::scales_fit(scale, scale), "load_packed: scale %g is outside the fused kernel's range "
                "(mi_isp_load_packed_scale_supported); resize separately", (double)scale);
     rtile::RParams rp = {};
     rp.t = p; rp.Hd = Hd; rp.Wd = Wd; rp.s0 = scale; rp.s1 = scale;
-    return rtile::launch(rp, work_dtype, pattern, (hipStream_t)stream);
+    if (int rc = rtile::launch(rp, work_dtype, pattern, (hipStream_t)stream)) return rc;
+    if (sub) return ew::subsample(rgb, sub, Hd, Wd, sub_stride, work_dtype, (hipStream_t)stream);
+    return 0;
   }
   MI_REQUIRE(Hd == H && Wd == W, "load_packed: output shape must equal the frame when scale <= 0");
   p.vec_store = vec_store_ok(rgb, W, work_dtype);
@@ -157,9 +161,34 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
     strm::SArgs a = {};
     a.t = p;
     strm::geometry(H, W, a);
-    return strm::launch(a, work_dtype, pattern, strm::S_STORE, (hipStream_t)stream);
+    if (sub && sub_stride == 8) { a.sub = sub; a.sub_w = (W + 7) / 8; }   // the metering subsample on the way
+    if (int rc = strm::launch(a, work_dtype, pattern, strm::S_STORE, (hipStream_t)stream)) return rc;
+    if (sub && sub_stride != 8) return ew::subsample(rgb, sub, H, W, sub_stride, work_dtype, (hipStream_t)stream);
+    return 0;
   }
-  return tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream);
+  if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream)) return rc;
+  if (sub) return ew::subsample(rgb, sub, H, W, sub_stride, work_dtype, (hipStream_t)stream);
+  return 0;
+}
+
+extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,
+                                  int pattern, const float* ccm9, int work_dtype, int Hd, int Wd, float scale,
+                                  void* stream) {
+  return load_packed_impl(packed, rgb, H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd, scale, nullptr, 0, stream);
+}
+
+extern "C" int mi_isp_load_packed_metered_is_fused(int H, int W, int bits, int ids_format, int work_dtype, int sub_stride) {
+  if (bits != 12 || ids_format || sub_stride != 8 || H <= 0 || W <= 0) return 0;
+  tile::Params p = {};
+  p.H = H; p.W = W; p.src_kind = tile::SRC_PACKED12; p.src_fast = ((int64_t)W * 3 / 2) % 4 == 0; p.in_scale = 1.f;
+  return strm::supported(p, work_dtype) && (int64_t)H * W * 3 * (int64_t)mi_dtype_size(work_dtype) < (int64_t)strm::INVALID_OFF ? 1 : 0;
+}
+
+extern "C" int mi_isp_load_packed_metered(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,
+                                          int pattern, const float* ccm9, int work_dtype, int Hd, int Wd, float scale,
+                                          void* sub, int sub_stride, void* stream) {
+  MI_REQUIRE(sub && sub_stride >= 1, "load_packed_metered: need a subsample buffer and a positive stride");
+  return load_packed_impl(packed, rgb, H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd, scale, sub, sub_stride, stream);
 }
 
 extern "C" int mi_isp_load_packed_scale_supported(float scale) { return rtile::scales_fit(scale, scale) ? 1 : 0; }

@@ -21,6 +21,9 @@ int tonemap_reinhard_tail(const void* src, void* dst, int H, int W, int in_dtype
                           float intensity, float la, float ca, float* ws, int which, const PullSrc& bounds,
                           hipStream_t s);
 
+// image[::stride, ::stride] -> dense (ceil(H / stride), ceil(W / stride), 3) image of the same dtype
+int subsample(const void* img, void* sub, int H, int W, int stride, int dtype, hipStream_t s);
+
 // ISP reinhard scalars from state9 -> FrameParams (camera_isp.py:186-195)
 int isp_reinhard_prep(const float* state9, float* fp, float intensity, float ca, hipStream_t s);
 

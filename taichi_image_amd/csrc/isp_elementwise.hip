@@ -481,6 +481,8 @@ struct PassArgs {
   const float* isp_state9;  // PM_ISP_RH_P1: camera_isp.py:186-195 evaluated per block (NULL: read fp)
   int no_nan;               // the source image holds no NaN (written by the tile kernel's clamping store)
   int pull_maxout_n;        // PM_ISP_RH_P2: partial maxima per image at partials[part_stride + y * n + i] (0: read maxouts)
+  int part_flip;            // PM_ISP_RH_P2, batched: grid row y reads the partial maxima of row n - 1 - y (pass 1 ran over the
+                            // reversed list, see mi_isp_reinhard_batch)
 };
 
 // camera_isp.py:186-195: the Reinhard scalars of the ISP path from the metering 9-vector
@@ -571,6 +573,9 @@ template <class TI, class TO, int MODE>
 __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArgs a) {
 #pragma clang fp contract(fast)
   __shared__ float red[PASS_THREADS / 64][8];
+  // (The pointer lists are indexed by blockIdx.y itself and nothing derived from it: with a computed index the compiler
+  // copies the 1.2 KB argument struct into scratch, per thread, to index it - 2.4 x the time of both ISP passes.  The
+  // host orders the lists instead.)
   const TI* src = static_cast<const TI*>(a.batched ? a.srcs.p[blockIdx.y] : a.src);
   TO* dst = static_cast<TO*>(a.batched ? const_cast<void*>(a.dsts.p[blockIdx.y]) : a.dst);
   TI* inplace = a.batched ? const_cast<TI*>(src) : static_cast<TI*>(a.inplace);
@@ -629,7 +634,8 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   if constexpr (MODE == PM_ISP_RH_P2) {
     if (a.batched && a.pull_maxout_n > 0) {
       // max_out of this block's image (camera_isp.py:190,213): fold the partial maxima pass 1 left
-      const float* pm = a.partials + a.part_stride + (size_t)blockIdx.y * a.pull_maxout_n;
+      const int prow = a.part_flip ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+      const float* pm = a.partials + a.part_stride + (size_t)prow * a.pull_maxout_n;
       float m = -__builtin_inff();
       for (int i = threadIdx.x; i < a.pull_maxout_n; i += PASS_THREADS) m = fmaxf(m, pm[i]);
       m = wave_max(m);
@@ -891,6 +897,20 @@ __global__ __launch_bounds__(EW_THREADS) void isp_p2_yuv420_kernel(const ew::Ptr
   }
 }
 
+// image[::stride, ::stride] as a dense (hs, ws, 3) image: what ISP.update_metering reads (camera_isp.py:168-170), for the
+// loaders that do not leave it on the way (mi_isp_load_packed_metered)
+template <class T>
+__global__ __launch_bounds__(EW_THREADS) void subsample_kernel(const T* __restrict__ img, T* __restrict__ sub, int H, int W, int stride) {
+  const int hs = (H + stride - 1) / stride, ws = (W + stride - 1) / stride;
+  const int n = hs * ws;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int sr = i / ws, sc = i - sr * ws;
+    const T* p = img + ((size_t)(sr * stride) * W + (size_t)sc * stride) * 3;
+    T* q = sub + (size_t)i * 3;
+    q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8 metering on the stride-subsampled images (camera_isp.py:142-175), two data passes.
 // grid = (blocks_per_image, n_images); partial index = blockIdx.y * gridDim.x + blockIdx.x + base
@@ -1089,6 +1109,19 @@ static int launch_pass(int mode, int in_dtype, int out_dtype, const PassArgs& a,
 static bool vec_ok(const void* p, int dtype);
 
 namespace ew {
+int subsample(const void* img, void* sub, int H, int W, int stride, int dtype, hipStream_t s) {
+  const int hs = (H + stride - 1) / stride, ws = (W + stride - 1) / stride;
+  int blocks = (hs * ws + EW_THREADS - 1) / EW_THREADS;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  return dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((subsample_kernel<T>), dim3(blocks), dim3(EW_THREADS), 0, s, static_cast<const T*>(img), static_cast<T*>(sub), H, W, stride);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+}
+
 int tail_blocks(int H, int W) { return pass_blocks((int64_t)H * W, mi_partial_cap(H, W)); }
 // The three data passes after the bounds pass of tonemap.py:146-154, chained by pulled finalizes
 // (PassArgs::pull_mode): pass 1 folds the bounds partials `bounds` of whoever produced the image,
@@ -1537,8 +1570,25 @@ extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, 
     int nb = pass_blocks(a.n_px, cap / m > 0 ? cap / m : 1);
     float* maxouts = partials + (size_t)2 * cap;           // partial row 2: unused by the 2-row reductions
     a.maxouts = maxouts;
+    // Zig-zag over the images: the blocks of a batched launch are dispatched image by image, and what a pass touched last
+    // is what the 256 MB Infinity Cache still holds.  The caller produced the images in list order (load_packed12 per
+    // camera), so pass 1 starts with the LAST image; it leaves p of the first image last, so pass 2 runs forward again.
+    // At 4K (6 x 75.5 MB) about half of each pass's reads then never reach HBM (profiles/r03_isp_order.txt).
+    int order1 = 1, order2 = 0;
+#ifdef MI_ISP_MEASURE
+    if (const char* o = getenv("MI_ISP_ORDER")) { order1 = o[0] == 'r'; order2 = o[0] && o[1] == 'r'; }
+#endif
+    auto set_lists = [&](int reversed) {
+      for (int i = 0; i < m; ++i) {
+        const int j = reversed ? m - 1 - i : i;
+        a.srcs.p[i] = images[i0 + j]; a.dsts.p[i] = outs[i0 + j];
+      }
+    };
+    set_lists(order1);
     if (int rc = launch_pass(PM_ISP_RH_P1, dtype, MI_U8, a, nb, s, m)) return rc;
     a.pull_maxout_n = nb;                                    // max_out per image folded in pass 2's prologue
+    set_lists(order2);
+    a.part_flip = order1 != order2;                          // pass 1 left image j's maxima in the row of ITS list position
     if (int rc = launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s, m)) return rc;
   }
   return 0;

@@ -63,6 +63,11 @@ struct SArgs {
   float n_px, intensity;  // for the pulled finalize steps
   float* fp_w;            // FrameParams (device), written by block 0 of the pulling passes
   int bounds_post;        // FIN_BOUNDS post-processing of the raw bounds: 1 = clamp, 2 = clamp + f16 rounding
+  // S_STORE: the stride-8 subsample ISP.update_metering gathers from the image (camera_isp.py:168-170: image[::8, ::8]),
+  // written on the way - (ceil(H / 8), ceil(W / 8), 3) work-dtype elements - or NULL.  A lane's unit starts at a
+  // multiple of 8 columns, so the sample of a row r % 8 == 0 is the lane's first pixel.
+  void* sub;
+  int sub_w;              // ceil(W / 8)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -658,6 +663,17 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
       } else {
 #pragma unroll
         for (int j = 0; j < 24; ++j) t[j] = clamp01(v[j]);
+      }
+      if constexpr (EPI == S_STORE) {
+        if (a.sub && (row & 7) == 0 && col_ok) {         // (row: wave-uniform)
+          E* sp = static_cast<E*>(a.sub) + ((size_t)(row >> 3) * a.sub_w + (size_t)(c0 >> 3)) * 3;
+          if constexpr (sizeof(E) == 2) {
+            uint16_t* s16 = reinterpret_cast<uint16_t*>(sp);
+            s16[0] = (uint16_t)(pk[0] & 0xFFFFu); s16[1] = (uint16_t)(pk[0] >> 16); s16[2] = (uint16_t)(pk[1] & 0xFFFFu);
+          } else {
+            sp[0] = (E)t[0]; sp[1] = (E)t[1]; sp[2] = (E)t[2];
+          }
+        }
       }
       if constexpr (EPI == S_STORE || EPI == S_STORE_BOUNDS) {
         const uint32_t row_base = (uint32_t)row * out_pitch + band_base;

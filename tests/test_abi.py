@@ -146,3 +146,22 @@ def test_whole_frame_kernel_uses_no_scratch():
     for i, (kernels, spills, scratch) in enumerate(results):
         assert len(kernels) == 2 and len(spills) == 2 and len(scratch) == 2, (i, kernels, spills, scratch)
         assert spills == [0, 0] and scratch == [0, 0], (i, kernels, spills, scratch)
+
+
+def test_no_kernel_of_the_library_touches_scratch():
+    """Read from the code objects inside libmi355_isp.so (scripts/kernel_resources.py): no kernel spills registers and
+    none has a private segment.  Besides spills this catches by-value argument structs that the compiler copies to scratch
+    to index them - a computed index into the batched passes' pointer lists did that in round 3 and cost 2.4 x."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm tools not available")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from taichi_image_amd import _native
+    res = mod.kernel_resources(_native.LIB_PATH)
+    assert len(res) > 300, len(res)
+    assert any("frame_kernel" in k for k in res) and any("rgb_pass_kernel" in k for k in res)
+    bad = {k: v for k, v in res.items() if v["scratch"] or v["vgpr_spills"]}
+    assert not bad, bad

@@ -711,3 +711,46 @@ def test_isp_tonemap_reinhard_yuv420_fused(ti, rng, dev, cam):
     d = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, transform=ti.ImageTransform.flip_horiz)
     ic, id_ = [c.load_packed12(frames[0])], [d.load_packed12(frames[0])]
     assert torch.equal(d.tonemap_reinhard_yuv420(id_, gamma=0.6)[0], color.rgb_yuv420_image(c.tonemap_reinhard(ic, gamma=0.6)[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam,shape,rw", [("Camera16", (200, 512), 0), ("Camera32", (72, 264), 0), ("Camera16", (192, 512), 256),
+                                          ("Camera16", (70, 200), 0)])
+def test_load_packed_leaves_the_metering_subsample(ti, rng, dev, cam, shape, rw):
+    """load_packed12 hands update_metering the stride-8 subsample it would otherwise gather (camera_isp.py:168-170): the
+    dense copy equals image[::8, ::8] bit for bit (written by the streaming load kernel itself; frames it does not take,
+    and resized loads, carry no subsample), metering on it gives the bits of metering on the images, and an image that was
+    written to through torch afterwards falls back to the gather.  The C entry's gather fallback is checked directly."""
+    H, W = shape
+    packed = [natural_packed12(np.random.default_rng(40 + k), H, W) for k in range(3)]
+    frames = [torch.from_numpy(p).to(dev) for p in packed]
+
+    def fresh():
+        return getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.3, resize_width=rw, device=dev)
+    a, b = fresh(), fresh()
+    for step in range(2):
+        imgs = [a.load_packed12(f) for f in frames]
+        fused = rw == 0 and W % 8 == 0
+        for im in imgs:
+            assert hasattr(im, "_mi_metering_sub") == fused        # only when the load kernel itself writes it
+            if fused:
+                sub, stride, ver = im._mi_metering_sub
+                assert stride == 8 and torch.equal(sub, im[::8, ::8]), "subsample differs from image[::8, ::8]"
+        plain = [im.clone() for im in imgs]                         # no tag: the strided gather
+        a.update_metering(imgs)
+        b.update_metering(plain)
+        assert torch.equal(a.metrics, b.metrics), (a.metrics, b.metrics)
+    # the C entry for a frame the fused path does not take (stride 4): the gather behind the load fills the buffer
+    from taichi_image_amd import _native
+    if rw == 0 and cam == "Camera16":
+        rgb = torch.empty((H, W, 3), dtype=torch.float16, device=dev)
+        sub4 = torch.zeros(((H + 3) // 4, (W + 3) // 4, 3), dtype=torch.float16, device=dev)
+        _native.check(_native.lib().mi_isp_load_packed_metered(frames[0].data_ptr(), rgb.data_ptr(), H, W, 12, 0, 0, None, ti.types.f16.code,
+                                                               H, W, 0.0, sub4.data_ptr(), 4, _native.stream_ptr(dev)))
+        assert torch.equal(sub4, rgb[::4, ::4]) and torch.equal(rgb, a.load_packed12(frames[0]))
+    imgs = [a.load_packed12(f) for f in frames]
+    imgs[1].mul_(0.5)                                               # torch wrote to it: the tag is stale and must not be used
+    plain = [im.clone() for im in imgs]
+    a.update_metering(imgs)
+    b.update_metering(plain)
+    assert torch.equal(a.metrics, b.metrics)
