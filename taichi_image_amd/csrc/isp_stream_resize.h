@@ -14,8 +14,12 @@
 //
 // Ownership: a wave owns the source band [col0, col0 + 8 * stride_units) x [r_begin, r_end) and produces the
 // destination pixels whose 2 x 2 source quad STARTS there (interpolate.py:24-34: quad origin = min(trunc(i / s),
-// n - 2)); it therefore also demosaics one more unit to the right and one more row below (the quads' second
-// column / row).  Bands are 57-63 units wide so that the extra unit fits the 64 lanes.
+// n - 2)) - with the band's first and last destination column moved up to the next multiple of 4 (align4): a lane
+// emits 4 destination pixels = 24 bytes = three 8-byte stores, and with ragged band ends EVERY wave had a lane whose
+// four pixels straddled the end, which sent the whole wave through the element-store path (12 two-byte store
+// instructions per row on top of the 3 real ones).  The wave therefore demosaics two more units to the right (the
+// quads' second column, and up to 3 destination pixels borrowed from the next band) and one more row below.  Bands are
+// 56-62 units wide so that the extra units fit the 64 lanes.
 //
 // Arithmetic: bit-exact against oracle isp_load_packed12 (same demosaic; p = I / scale by true division,
 // mix(x, y, a) = x (1 - a) + y a uncontracted, rows first, then columns).
@@ -36,8 +40,9 @@ struct RSArgs {
   Params t;                 // source description (tile::Params); t.dst = the (Hd, Wd, 3) f16 output
   int Hd, Wd;
   float s0, s1;             // interpolate.py:60-66: p = (r / s0, c / s1)
-  int stride_units;         // units (8 px) a band owns; its wave covers stride_units + 1
+  int stride_units;         // units (8 px) a band owns; its wave covers stride_units + 2
   int bands_x, rows_per_wave, n_waves, n_blocks;
+  int align4;               // destination columns are dealt to the bands in whole groups of 4 (see the kernel)
 };
 
 // quad origin of destination index i along one axis: min(trunc(i / s), n - 2)   (n >= 2)
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
   const int r_begin = by * a.rows_per_wave;
   const int r_own_end = wave_ok ? (r_begin + a.rows_per_wave < p.H ? r_begin + a.rows_per_wave : p.H) : r_begin;
   const int r_last = r_own_end < p.H ? r_own_end : p.H - 1;         // last row to demosaic (one beyond the owned ones)
-  const bool col_ok = wave_ok && c0 < p.W && lane <= a.stride_units;
+  const bool col_ok = wave_ok && c0 < p.W && lane <= a.stride_units + 1;
   uint4 (*ring)[ROW_BYTES / 16] = ring_all[wave];
 
   // ---- packed source rows (as stream_kernel) ----
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
   const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID_OFF;
-  const bool last_lane = lane == a.stride_units || lane == 63;
+  const bool last_lane = lane == a.stride_units + 1 || lane == 63;
   const bool ext_ok = col_ok && ((lane == 0 && c0 > 0) || (last_lane && c0 + 8 < p.W));
   const uint32_t ext_off = ext_ok ? (uint32_t)c0 * 3 / 2 + (lane == 0 ? -4 : 12) : INVALID_OFF;
   auto load_row = [&](int r, uint32_t (&d)[4]) {
@@ -109,8 +114,13 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
 
   // ---- destination geometry of this wave ----
   const int own_c_end = bx + 1 < a.bands_x ? col0 + a.stride_units * 8 : p.W;      // quad origins [col0, own_c_end)
-  const int cd_begin = wave_ok ? first_with_origin(col0, a.s1, p.W, a.Wd) : 0;
-  const int cd_end = wave_ok ? (bx + 1 < a.bands_x ? first_with_origin(own_c_end, a.s1, p.W, a.Wd) : a.Wd) : 0;
+  auto band_edge = [&](int src_col) {                  // first destination column of the band that starts at src_col
+    const int c = first_with_origin(src_col, a.s1, p.W, a.Wd);
+    const int c4 = a.align4 ? (c + 3) & ~3 : c;
+    return c4 < a.Wd ? c4 : a.Wd;
+  };
+  const int cd_begin = wave_ok && bx > 0 ? band_edge(col0) : 0;
+  const int cd_end = wave_ok ? (bx + 1 < a.bands_x ? band_edge(own_c_end) : a.Wd) : 0;
   const int rd_begin = wave_ok ? first_with_origin(r_begin, a.s0, p.H, a.Hd) : 0;
   const int rd_end = wave_ok ? (r_own_end < p.H ? first_with_origin(r_own_end, a.s0, p.H, a.Hd) : a.Hd) : 0;
   const __amdgpu_buffer_rsrc_t drsrc =
@@ -139,6 +149,12 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
   ColTap tap0[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) tap0[j] = col_tap(cg0 + 4 * lane + j);
+  // the usual case, for the whole wave: the first column tap is the quad's first column, the second its second
+  // (index_clamped, interpolate.py:20-21, only bites in the image's last column) - no selects in the emission then
+  bool plain0 = true;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) plain0 = plain0 && !tap0[j].sel_a && tap0[j].sel_b;
+  const bool plain_wave = __builtin_amdgcn_ballot_w64(!plain0) == 0;
 
   MI_SSTAMP(0);
   // ---- prologue ----
@@ -167,33 +183,54 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
   int next_r = rd_begin;                               // next destination row to emit
 
   // one destination row: both source rows of its quads are in the ring
-  auto emit = [&](int r) {
+  auto emit = [&](int r) __attribute__((always_inline)) {
     const float pr = (float)r / a.s0;                  // wave-uniform
     const int ir = (int)pr;
     const float fr = vgpr(pr - (float)ir), fr1 = vgpr(1.0f - (pr - (float)ir));
     const int ra = ir < p.H - 1 ? ir : p.H - 1, rb = ir + 1 < p.H - 1 ? ir + 1 : p.H - 1;      // index_clamped
     const char* row_a = reinterpret_cast<const char*>(ring[ra % RING]);
     const char* row_b = reinterpret_cast<const char*>(ring[rb % RING]);
-    auto group = [&](int gbase, const ColTap (&tap)[4]) {
-      half_t oh[12];
+    auto group = [&](int gbase, const ColTap (&tap)[4], auto plain_c) __attribute__((always_inline)) {
+      constexpr bool PLAIN = decltype(plain_c)::value;
+      float of[12];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint2 a0 = *reinterpret_cast<const uint2*>(row_a + tap[j].off0), a1 = *reinterpret_cast<const uint2*>(row_a + tap[j].off1);
         const uint2 b0 = *reinterpret_cast<const uint2*>(row_b + tap[j].off0), b1 = *reinterpret_cast<const uint2*>(row_b + tap[j].off1);
-        half_t ha[8], hb[8];                              // [0..3] pixel qc, [4..7] pixel qc + 1 (r, g, b, pad)
-        __builtin_memcpy(ha, &a0, 8); __builtin_memcpy(ha + 4, &a1, 8);
-        __builtin_memcpy(hb, &b0, 8); __builtin_memcpy(hb + 4, &b1, 8);
         const float fc = tap[j].fc, fc1 = 1.0f - tap[j].fc;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          // rows first (interpolate.py:28-33), then the column taps pick their column
-          const float m0 = (float)ha[ch] * fr1 + (float)hb[ch] * fr;
-          const float m1 = (float)ha[4 + ch] * fr1 + (float)hb[4 + ch] * fr;
-          const float y1 = tap[j].sel_a ? m1 : m0;
-          const float y2 = tap[j].sel_b ? m1 : m0;
-          oh[3 * j + ch] = cast_out<E>(y1 * fc1 + y2 * fc);                        // intensity scale 1 (same dtype)
-        }
+        // rows first (interpolate.py:28-33): m = x (1 - a) + y a, two products and a sum, each rounded (no contraction).
+        // A product takes its f16 factor straight from the packed word (v_fma_mix_f32 with a zero addend: the half is
+        // widened exactly, the product rounded once to fp32 - the bits of converting first and multiplying, without the
+        // twelve conversions per pixel; all factors are >= 0, so the zero addend changes nothing).
+        auto channel = [&](auto hi_c, uint32_t xa, uint32_t xb, uint32_t xa1, uint32_t xb1) __attribute__((always_inline)) {
+          constexpr bool HI = decltype(hi_c)::value;
+          float pa, pb, qa, qb;
+          if constexpr (HI) {
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(pa) : "v"(xa), "v"(fr1));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(pb) : "v"(xb), "v"(fr));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(qa) : "v"(xa1), "v"(fr1));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(qb) : "v"(xb1), "v"(fr));
+          } else {
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(pa) : "v"(xa), "v"(fr1));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(pb) : "v"(xb), "v"(fr));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(qa) : "v"(xa1), "v"(fr1));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(qb) : "v"(xb1), "v"(fr));
+          }
+          const float m0 = pa + pb, m1 = qa + qb;
+          // then the column taps pick their column
+          const float y1 = PLAIN ? m0 : (tap[j].sel_a ? m1 : m0);
+          const float y2 = PLAIN ? m1 : (tap[j].sel_b ? m1 : m0);
+          return f32_rounded(y1 * fc1 + y2 * fc);                                   // intensity scale 1 (same dtype)
+        };
+        of[3 * j + 0] = channel(std::false_type{}, a0.x, b0.x, a1.x, b1.x);       // r: low half of the first word
+        of[3 * j + 1] = channel(std::true_type{}, a0.x, b0.x, a1.x, b1.x);        // g: its high half
+        of[3 * j + 2] = channel(std::false_type{}, a0.y, b0.y, a1.y, b1.y);       // b: low half of the second word
       }
+      half_t oh[12];                                        // RNE to f16, in pairs (v_cvt_pk_f16_f32)
+      uint32_t opk[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(opk[k]) : "v"(of[2 * k]), "v"(of[2 * k + 1]));
+      __builtin_memcpy(oh, opk, 24);
       uint32_t outp[6];
       __builtin_memcpy(outp, oh, 24);
       const int cl = gbase + 4 * lane;
@@ -213,14 +250,15 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
         }
       }
     };
-    group(cg0, tap0);
+    if (plain_wave) group(cg0, tap0, std::true_type{});
+    else group(cg0, tap0, std::false_type{});
     if (cg0 + 256 < cd_end) {                            // more than 256 destination columns per band: upscaling
       asm volatile("" ::: "memory");                     // keep this a real branch (the taps are recomputed inside)
       for (int gbase = cg0 + 256; gbase < cd_end; gbase += 256) {
         ColTap tap[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) tap[j] = col_tap(gbase + 4 * lane + j);
-        group(gbase, tap);
+        group(gbase, tap, std::false_type{});
       }
     }
   };
@@ -297,10 +335,14 @@ static inline bool supported(const Params& p, int work_dtype, const void* dst, i
 
 static inline void geometry(int H, int W, RSArgs& a) {
   const int units = W / 8;
-  a.bands_x = units > 1 ? (units - 1 + 62) / 63 : 1;
-  a.stride_units = units > 1 ? (units - 1 + a.bands_x - 1) / a.bands_x : 1;
-  // the last band may own one unit more than the others need: its wave still fits (stride_units + 1 <= 64 lanes cover
-  // every unit because bands_x * stride_units >= units - 1)
+  a.bands_x = units > 2 ? (units - 2 + 61) / 62 : 1;
+  a.stride_units = units > 2 ? (units - 2 + a.bands_x - 1) / a.bands_x : 1;
+  // the last band may own two units more than the others need: its wave still fits (stride_units + 2 <= 64 lanes cover
+  // every unit because bands_x * stride_units >= units - 2).
+  // align4: a band borrows up to 3 destination columns from its right neighbour; their quads reach at most
+  // 3 * ceil(1 / s1) + 1 source columns past the band's own ones, which the second extra unit must hold
+  const int step = (int)ceilf(1.0f / a.s1);
+  a.align4 = 3 * step + 2 <= 16 ? 1 : 0;
   int rpw = (int)(((long)H * a.bands_x + 2047) / 2048);
   rpw = (rpw + 1) / 2 * 2;
   if (rpw < 4) rpw = 4;
