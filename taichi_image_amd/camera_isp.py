@@ -7,7 +7,7 @@ two-pass elementwise kernels with wave-shuffle reductions.
 
 Deliberate differences from the reference (see DESIGN.md "quirks"):
  * `_process_image` forwards `self.bayer_pattern` (the reference drops it and always demosaics
-   RGGB, camera_isp.py:372); identical for RGGB.
+   RGGB, camera_isp.py:372); identical for RGGB.  `reference_quirks=True` reproduces the reference.
  * tonemap parameters are runtime floats (the reference re-JITs per value).
  * NaN / out-of-range float->u8 casts are defined (0 / saturate) where the reference is undefined.
 """
@@ -87,7 +87,8 @@ def camera_isp(name: str, dtype=types.f32):
                      transform: interpolate.ImageTransform = interpolate.ImageTransform.none,
                      device: torch.device = torch.device('cuda', 0),
                      metering_stride: int = 8,
-                     process_group=None):
+                     process_group=None,
+                     reference_quirks: bool = False):
             _typecheck("bayer_pattern", bayer_pattern, bayer.BayerPattern)
             _typecheck("scale", scale, float, optional=True)
             _typecheck("resize_width", resize_width, int)
@@ -100,6 +101,11 @@ def camera_isp(name: str, dtype=types.f32):
             assert scale is None or resize_width == 0, "Cannot specify both scale and resize_width"
 
             self.bayer_pattern = bayer_pattern
+            # reference_quirks=True: demosaic as the reference does - ISP._process_image calls bayer_to_rgb WITHOUT its
+            # pattern (camera_isp.py:371-373), so every camera is demosaiced as RGGB whatever bayer_pattern says.  For
+            # comparisons against the reference's own outputs; the default honours the pattern.
+            _typecheck("reference_quirks", reference_quirks, bool)
+            self.reference_quirks = reference_quirks
             self.moving_alpha = moving_alpha
             self.scale = scale
             self.resize_width = resize_width
@@ -114,6 +120,10 @@ def camera_isp(name: str, dtype=types.f32):
             self.device = device
             # one-process-per-GPU sharding: statistics are all-reduced over this group (RCCL)
             self.process_group = process_group
+
+        @property
+        def _demosaic_pattern(self):
+            return bayer.BayerPattern.RGGB if self.reference_quirks else self.bayer_pattern
 
         def set(self, moving_alpha: Optional[float] = None, resize_width: Optional[int] = None,
                 scale: Optional[float] = None,
@@ -208,13 +218,13 @@ def camera_isp(name: str, dtype=types.f32):
             rgb = torch.empty((hd, wd, 3), dtype=torch_dtype, device=self.device)
             if not fused and scale > 0:                  # a scale the fused kernel does not take: resize separately
                 _native.check(L.mi_isp_load_packed(
-                    src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
+                    src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value,
                     _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, 0.0, _native.stream_ptr(self.device)))
                 return self.resize_image(rgb)
             st = self.metering_stride
             if fused or not L.mi_isp_load_packed_metered_is_fused(h, w, bits, int(bool(ids_format)), dtype.code, st):
                 _native.check(L.mi_isp_load_packed(
-                    src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
+                    src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value,
                     _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, float(scale) if fused else 0.0,
                     _native.stream_ptr(self.device)))
                 return rgb
@@ -222,7 +232,7 @@ def camera_isp(name: str, dtype=types.f32):
             # the load kernel holds those pixels anyway, the strided gather over six 4K images costs 25 us per call
             sub = torch.empty(((hd + st - 1) // st, (wd + st - 1) // st, 3), dtype=torch_dtype, device=self.device)
             _native.check(L.mi_isp_load_packed_metered(
-                src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self.bayer_pattern.value,
+                src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value,
                 _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, 0.0,
                 sub.data_ptr(), st, _native.stream_ptr(self.device)))
             rgb._mi_metering_sub = (sub, st, rgb._version)    # valid while nobody writes to the image through torch
@@ -247,7 +257,7 @@ def camera_isp(name: str, dtype=types.f32):
 
         def _process_image(self, cfa):
             """camera_isp.py:371-373."""
-            rgb = bayer.bayer_to_rgb(cfa, pattern=self.bayer_pattern, correct_colors=self.color_correct_matrix)
+            rgb = bayer.bayer_to_rgb(cfa, pattern=self._demosaic_pattern, correct_colors=self.color_correct_matrix)
             return self.resize_image(rgb)
 
         def _metering_images(self, images, t, prev):

@@ -357,6 +357,25 @@ def test_whole_frame_timeout_is_reported_and_repaired(ti, dev, scenes):
     assert _error_word(ti, 3072, 4096, dev) == 0 and torch.equal(again, good)
 
 
+@pytest.mark.parametrize("out", ["f16", "u8"])
+def test_config3b_per_axis_resize_at_full_size(ti, dev, scenes, out):
+    """BASELINE config 3's nominal 1920 x 1080: not reachable through Camera16 (uniform scale only) but
+    through the resize primitive's per-axis scale (interpolate.py:71-86,128-139) = (1080 / 3072, 1920 / 4096) on the
+    demosaiced 4K f16 image - bit-exact against the oracle at full size."""
+    from taichi_image_amd import interpolate
+    packed = packed_from(scenes[3])
+    isp = ti.Camera16(ti.BayerPattern.RGGB, device=dev)
+    rgb = isp.load_packed12(torch.from_numpy(packed).to(dev))
+    ref_rgb = O.isp_load_packed12(packed, "f16")
+    assert np.array_equal(rgb.cpu().numpy().view(np.uint16), ref_rgb.view(np.uint16))
+    scale = (1080 / 3072, 1920 / 4096)
+    assert scale == (0.3515625, 0.46875)
+    got = interpolate.resize_bilinear(rgb, (1920, 1080), scale=scale, dtype=getattr(ti.types, out))
+    ref = O.resize_bilinear(ref_rgb, (1920, 1080), scale=scale, dtype=out)
+    assert got.shape == (1080, 1920, 3)
+    assert np.array_equal(got.cpu().numpy().view(np.uint8), ref.view(np.uint8)), "per-axis resize at 4K is not bit-exact"
+
+
 # ---- boundary: one C call per camera group (mi_isp_camera_frame_batch), straight through ctypes ------------------
 @pytest.mark.parametrize("tonemap,resize_width", [(0, 0), (0, 960), (1, 960)])
 def test_camera_frame_batch_through_the_c_abi(ti, dev, rng, tonemap, resize_width):

@@ -568,6 +568,25 @@ def test_isp_constructor_and_set(ti, dev):
     assert ti.Camera16.__qualname__ == "Camera16" and callable(ti.Camera16.reinhard_kernel)
 
 
+@pytest.mark.parametrize("cam,work", [("Camera16", "f16"), ("Camera32", "f32")])
+def test_isp_reference_quirks_drop_the_pattern(ti, rng, dev, cam, work):
+    """ISP._process_image of the reference calls bayer_to_rgb without its pattern (camera_isp.py:371-373): every camera
+    is demosaiced as RGGB.  reference_quirks=True reproduces that (strict comparison with the reference's outputs), the
+    default honours bayer_pattern; for an RGGB camera the two agree."""
+    H, W = 64, 96
+    packed = natural_packed12(rng, H, W, pattern=O.BGGR)
+    frame = torch.from_numpy(packed).to(dev)
+    honest = getattr(ti, cam)(ti.BayerPattern.BGGR, device=dev).load_packed12(frame)
+    quirky = getattr(ti, cam)(ti.BayerPattern.BGGR, device=dev, reference_quirks=True).load_packed12(frame)
+    assert_exact(honest.cpu().numpy(), O.isp_load_packed12(packed, work, pattern=O.BGGR), "pattern honoured")
+    assert_exact(quirky.cpu().numpy(), O.isp_load_packed12(packed, work, pattern=O.RGGB), "pattern dropped, as the reference does")
+    assert not torch.equal(honest, quirky)
+    cfa16 = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+    q16 = getattr(ti, cam)(ti.BayerPattern.GRBG, device=dev, reference_quirks=True).load_16u(torch.from_numpy(cfa16))
+    r16 = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev).load_16u(torch.from_numpy(cfa16))
+    assert torch.equal(q16, r16)
+
+
 # ---- color/yuv_420.py (the step after the path) --------------------------------------------------
 @pytest.mark.parametrize("in_dt,out_dt", [("u8", None), ("f16", "u8"), ("f32", "f16"), ("u16", "u8"), ("f32", None)])
 @pytest.mark.parametrize("shape", [(2, 2), (6, 10), (64, 96)])
