@@ -412,7 +412,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 doc = json.load(open(tpath))
-                traffic = doc["kernels"]["whole_frame" if whole else f"pass{dom}"]["hbm_bytes"]
+                k = doc["kernels"]["whole_frame" if whole else f"pass{dom}"]
+                # per launch, like `achieved`: the profile's launch held frames_per_launch frames
+                traffic = int(k["hbm_bytes_per_frame"] * args.frames) if whole and "hbm_bytes_per_frame" in k else k["hbm_bytes"]
                 traffic_src = "profile-cited, not measured in this run: profiles/traffic_latest.json (" + doc.get("tag", "?") + ")"
             except Exception:
                 traffic = None

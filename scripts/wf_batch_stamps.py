@@ -45,3 +45,13 @@ d = np.diff(ab, axis=1)
 print(f"last frame, per wave, us spent between stamps (p50 / p90): " + "  ".join(f"{names[i + 1]}: {np.median(d[:, i]):.2f}/{np.percentile(d[:, i], 90):.2f}" for i in range(8)))
 pro = (S[f, :, 15] - S[f, :, 0]) / 100.0
 print(f"last frame: first four rows decoded {np.median(pro):.2f} us after the frame's start (p90 {np.percentile(pro, 90):.2f})")
+# the barriers of the last frame, absolute: the last record's post, then (role-0 wave of every block) all records seen, partial
+# fold left in LDS, and - in the block whose role 0 finished last - the scalars published
+for name, b0, post in (("barrier 0", 9, 2), ("barrier 2", 12, 6)):
+    last_post = (S[f, :, post].max() - t0) / 100.0
+    m = S[f, :, b0] != 0
+    seen = (S[f, m, b0] - t0) / 100.0; left = (S[f, m, b0 + 1] - t0) / 100.0
+    pub = S[f, :, b0 + 2]; pub = (pub[pub != 0] - t0) / 100.0
+    passed = (S[f, :, post + 1] - t0) / 100.0
+    print(f"{name}: last record posted {last_post:.2f}; all records seen p50 {np.median(seen):.2f} max {seen.max():.2f}; partial fold left p50 {np.median(left):.2f} "
+          f"max {left.max():.2f}; scalars published p50 {np.median(pub):.2f} max {pub.max():.2f} (n={len(pub)}); waves passed p50 {np.median(passed):.2f} max {passed.max():.2f}")
