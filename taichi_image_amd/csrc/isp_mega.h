@@ -150,8 +150,8 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
 struct FoldLds {
   unsigned ticket[4], done[4], flag[4];   // running counts over the frames of a launch: role = ticket % WAVES, flag = frames passed
   float mm[WAVES][4];
-  double sum[WAVES][5];
-  double keep[7];                         // barrier 0's totals of the speculative statistics, for barrier 1 (bounds other than (0, 1))
+  float sum[WAVES][5];
+  float keep[7];                          // barrier 0's totals of the speculative statistics, for barrier 1 (bounds other than (0, 1))
 };
 
 // Wait for the barrier whose records live in `area` and derive the scalars of the next phase.  Every wave of the block
@@ -238,11 +238,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   };
   unsigned long long missing = m.l2_first ? round(std::integral_constant<int, 1>{}) : ~0ull;
   while (missing != 0) {
-    missing = round(std::integral_constant<int, 16>{});
-    if (missing == 0) break;
-    // many records missing: the phase is still running elsewhere, poll rarely; few: the last arrivals, poll at once
-    const unsigned naps = __builtin_popcountll(missing) > 16 ? 4u * m.poll_sleep + 1u : m.poll_sleep;
-    for (unsigned z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
+    // (the budget is checked BEFORE the next round: a budget of 1 - tests/ - gives up on the first missing record)
     if (++spins > m.spin_limit) {                     // a peer is not resident: give up loudly instead of hanging
       if (lane == 0) {
         __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -250,10 +246,17 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       }
       break;
     }
+    // many records missing: the phase is still running elsewhere, poll rarely; few: the last arrivals, poll at once
+    const unsigned naps = spins > 1 && __builtin_popcountll(missing) > 16 ? 4u * m.poll_sleep + 1u : m.poll_sleep;
+    for (unsigned z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
+    missing = round(std::integral_constant<int, 16>{});
   }
   if (stamps && lane == 0 && role == 0) stamps[0] = MI_STAMP_NOW();
+  // The fold: fp32 (round 2 folded the sums in fp64 - 0.8 us of DPP trees per barrier with every wave of the chip
+  // waiting; 512 fp32 partials summed pairwise lose ~1e-7 relative, the scalars' contract is 1e-4).  The order is fixed
+  // (lanes, then roles), so every block derives the same bits.
   float mm[NMM > 0 ? NMM : 1];
-  double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  float sum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
@@ -268,7 +271,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
         if (k < NV) {
           const float x = __builtin_bit_cast(float, w3[e]);
           if (k < NMM) { if (real) mm[k] = (k & 1) ? fmaxf(mm[k], x) : fminf(mm[k], x); }
-          else sum[k - NMM] += real ? (double)x : 0.0;
+          else sum[k - NMM] += real ? x : 0.f;
         }
       }
     }
@@ -296,13 +299,13 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   if (finished == WAVES - 1) {
     // ---- the last role combines the partial folds (role order) and publishes the scalars ----
     if (lane == 0) {
-      double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      float tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int k = 0; k < NMM; ++k) {
         float x = fl.mm[0][k];
 #pragma unroll
         for (int r = 1; r < WAVES; ++r) x = (k & 1) ? fmaxf(x, fl.mm[r][k]) : fminf(x, fl.mm[r][k]);
-        tot[k] = (double)x;
+        tot[k] = x;
       }
       if (NV >= 7 || NV == 1) {
 #pragma unroll
@@ -312,9 +315,9 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       fa.fp = sh_fp; fa.n_px = a.n_px; fa.intensity = a.intensity; fa.la = a.t.la; fa.ca = a.t.ca;
       fa.bounds_post = a.bounds_post;
       if constexpr (NV == 9) {
-        ew::finalize_scalars<true>(ew::FIN_BOUNDS, fa, tot);
+        ew::finalize_scalars_fast(ew::FIN_BOUNDS, fa, tot);
         if (sh_fp[FP_LO] == 0.f && sh_fp[FP_INV] == 1.f) {
-          ew::finalize_scalars<true>(ew::FIN_STATS, fa, tot + 2);
+          ew::finalize_scalars_fast(ew::FIN_STATS, fa, tot + 2);
         } else {
 #pragma unroll
           for (int k = 0; k < 7; ++k) fl.keep[k] = tot[2 + k];     // raw gray min / max, (sum log2), sum gray, channel sums
@@ -324,17 +327,17 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
         // affine, the weights of rgb_gray sum to 1, and the clamp to [0, 1] is the identity between the image's own
         // bounds - so gray(n) = (gray(x) - lo) * inv, its min / max and every sum follow from the raw ones (within fp32
         // rounding: ~1e-7 relative, the contract of these scalars is 1e-4); only the sum of logarithms needs the pixels
-        // (phase B: tot[0]).
-        const double lo = (double)sh_fp[FP_LO], inv = (double)sh_fp[FP_INV], n = (double)a.n_px;
-        double t7[7];
+        // (phase B: tot[0]).  fp32 throughout: the sums are fp32 sums of 12.6 M values to begin with (~1e-7 relative),
+        // and n * lo takes away at most the part of them that the image's minimum accounts for.
+        const float lo = sh_fp[FP_LO], inv = sh_fp[FP_INV], nlo = a.n_px * sh_fp[FP_LO];
+        float t7[7];
         t7[0] = (fl.keep[0] - lo) * inv; t7[1] = (fl.keep[1] - lo) * inv;
         t7[2] = tot[0];
-        t7[3] = (fl.keep[3] - n * lo) * inv;
 #pragma unroll
-        for (int k = 4; k < 7; ++k) t7[k] = (fl.keep[k] - n * lo) * inv;
-        ew::finalize_scalars<true>(ew::FIN_STATS, fa, t7);
+        for (int k = 3; k < 7; ++k) t7[k] = (fl.keep[k] - nlo) * inv;
+        ew::finalize_scalars_fast(ew::FIN_STATS, fa, t7);
       } else {
-        ew::finalize_scalars<true>(FIN, fa, tot);
+        ew::finalize_scalars_fast(FIN, fa, tot);
       }
       if (stamps) stamps[2] = MI_STAMP_NOW();
       __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
