@@ -183,7 +183,18 @@ MI_DEV void wave_load24(const T* gptr, int lane, void* lbuf_, T (&t)[24]) {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <class T>
+// NT: stream the stores to memory (final outputs nobody on the chip reads back; see strm::ST_STREAM)
+template <bool NT, class U> MI_DEV void store_unit(U* p, const U& v) {
+  if constexpr (NT) {                                  // (the builtin takes clang vector types, not HIP's uint2 / uint4)
+    typedef uint32_t vec_t __attribute__((ext_vector_type(sizeof(U) / 4)));
+    vec_t x;
+    __builtin_memcpy(&x, &v, sizeof(U));
+    __builtin_nontemporal_store(x, reinterpret_cast<vec_t*>(p));
+  } else {
+    *p = v;
+  }
+}
+template <class T, bool NT = false>
 MI_DEV void wave_store24(T* gptr, int lane, void* lbuf_, const T (&t)[24]) {
   typedef typename IoUnit<T>::type U;
   constexpr int N = IoUnits<T>::value;
@@ -199,15 +210,15 @@ MI_DEV void wave_store24(T* gptr, int lane, void* lbuf_, const T (&t)[24]) {
     if ((reinterpret_cast<uintptr_t>(gptr) & 15) == 0) {
       const uint4* l4 = reinterpret_cast<const uint4*>(lbuf_);
       uint4* g4 = reinterpret_cast<uint4*>(gptr);
-      g4[lane] = l4[lane];
-      if (lane < 32) g4[64 + lane] = l4[64 + lane];
+      store_unit<NT>(g4 + lane, l4[lane]);
+      if (lane < 32) store_unit<NT>(g4 + 64 + lane, l4[64 + lane]);
       __builtin_amdgcn_wave_barrier();
       return;
     }
   }
   U* g = reinterpret_cast<U*>(gptr);
 #pragma unroll
-  for (int j = 0; j < N; ++j) g[j * 64 + lane] = lbuf[j * 64 + lane];
+  for (int j = 0; j < N; ++j) store_unit<NT>(g + j * 64 + lane, lbuf[j * 64 + lane]);
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -447,6 +447,14 @@ __global__ __launch_bounds__(EW_THREADS) void rgb_yuv420_vec_kernel(const TI* __
 // (camera_isp.py:177-227).  MODE selects the per-pixel work; reductions leave one partial per
 // block.
 // ---------------------------------------------------------------------------------------------
+// cache policy of the passes' stores: the in-place p of ISP pass 1 is read back by pass 2 (kept), the outputs of the
+// storing passes are final (streamed)
+#ifndef MI_NT_P1
+#define MI_NT_P1 false
+#endif
+#ifndef MI_NT_OUT
+#define MI_NT_OUT true
+#endif
 enum PassMode {
   PM_MINMAX = 0,        // bounds_func (util.py:50-60)
   PM_STATS = 1,         // linear_func(gamma 1) + metering_func (tonemap.py:78-103)
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
         TI ot[24];
 #pragma unroll
         for (int i = 0; i < 24; ++i) ot[i] = cast_out<TI>(o[i]);
-        wave_store24<TI>(inplace + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
+        wave_store24<TI, MI_NT_P1>(inplace + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
       } else {
         store24<TI>(inplace + px0 * 3, o, npx, a.vec_in);
       }
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
         TO ot[24];
 #pragma unroll
         for (int i = 0; i < 24; ++i) ot[i] = cast_out<TO>(o[i]);
-        wave_store24<TO>(dst + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
+        wave_store24<TO, MI_NT_OUT>(dst + (px0 - (int64_t)lane * 8) * 3, lane, wbuf, ot);
       } else if (a.transform == MI_T_NONE) {
         store24<TO>(dst + px0 * 3, o, npx, a.vec_out);
       } else {

@@ -800,15 +800,15 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     uint4* stage = xl[wave][RR < NL ? RR : 0];
     const uint32_t row_base = (uint32_t)(r_begin + RR) * out_pitch + band_base;
     switch (MI_CENSUS(p.out_dtype, MI_F16)) {
-      case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, q); break;
-      case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, q); break;
+      case MI_U8: wave_store_row_t<uint8_t, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, q); break;
+      case MI_U16: wave_store_row_t<uint16_t, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, q); break;
       default: {                                        // f16: pairs leave through v_cvt_pk_f16_f32 (half the conversions)
         uint32_t pk[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[j]) : "v"(q[2 * j]), "v"(q[2 * j + 1]));
         uint4 mine[3];
         __builtin_memcpy(mine, pk, sizeof(mine));
-        wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
+        wave_store_units<uint4, 3, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, mine);   // streamed: nobody reads the output back
         break;
       }
     }

@@ -169,19 +169,27 @@ MI_DEV void accumulate_row(const WinRow (&win)[6], const float (&wq)[8], float (
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t INVALID_OFF = 0x40000000u;       // 1 GiB: beyond any frame the stream kernels accept
 
-template <int UB> MI_DEV void buffer_store_unit(__amdgpu_buffer_rsrc_t rsrc, const void* val, uint32_t voff, uint32_t soff) {
+// AUX: cache policy bits of the store.  ST_STREAM = nt ("non-temporal"): a final output nobody on the chip reads again is
+// streamed to memory instead of being allocated in the write-back L2 - measured on the whole-frame kernel's phase D
+// (75.5 MB per frame, write-bound): 49.9 -> 46.7 us per frame (`sc1`, write-through, gives the same; nt on the packed
+// frame's LOADS gives nothing).  ST_KEEP = the default policy, for images the next kernel reads back.
+constexpr int ST_KEEP = 0, ST_STREAM = 2;
+#ifndef MI_ST_LOAD                 /* the image ISP.load_packed12 stores (the metering and the first tonemap pass read it back) */
+#define MI_ST_LOAD ST_KEEP
+#endif
+template <int UB, int AUX> MI_DEV void buffer_store_unit(__amdgpu_buffer_rsrc_t rsrc, const void* val, uint32_t voff, uint32_t soff) {
   if constexpr (UB == 16) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     u4 x; __builtin_memcpy(&x, val, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, voff, soff, AUX);
   } else {
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     u2 x; __builtin_memcpy(&x, val, 8);
-    __builtin_amdgcn_raw_buffer_store_b64(x, rsrc, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(x, rsrc, voff, soff, AUX);
   }
 }
 
-template <class U, int N>
+template <class U, int N, int AUX = ST_KEEP>
 MI_DEV void wave_store_units(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, const uint32_t (&lane_off)[6], int lane,
                              uint4* stage_, const U (&mine)[N]) {
   U* lb = reinterpret_cast<U*>(stage_);
@@ -196,12 +204,12 @@ MI_DEV void wave_store_units(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, con
     const int q = j * 64 + lane;
     const int sl = N == 6 ? q / 6 : 0;
     const U val = N == 6 ? lb[sl * P + (q - sl * 6)] : lb[q];
-    buffer_store_unit<(int)sizeof(U)>(rsrc, &val, lane_off[j], row_base);
+    buffer_store_unit<(int)sizeof(U), AUX>(rsrc, &val, lane_off[j], row_base);
   }
   __builtin_amdgcn_wave_barrier();
 }
 
-template <class T>
+template <class T, int AUX = ST_KEEP>
 MI_DEV void wave_store_row_t(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, const uint32_t (&lane_off)[6], int lane,
                              uint4* stage, const float (&v)[24]) {
   typedef typename IoUnit<T>::type U;
@@ -211,7 +219,7 @@ MI_DEV void wave_store_row_t(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, con
   for (int i = 0; i < 24; ++i) o[i] = cast_out<T>(v[i]);
   U mine[N];
   __builtin_memcpy(mine, o, sizeof(mine));
-  wave_store_units<U, N>(rsrc, row_base, lane_off, lane, stage, mine);
+  wave_store_units<U, N, AUX>(rsrc, row_base, lane_off, lane, stage, mine);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -680,11 +688,11 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
         if constexpr (sizeof(E) == 2) {
           uint4 mine[3];
           __builtin_memcpy(mine, pk, sizeof(mine));
-          wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
+          wave_store_units<uint4, 3, MI_ST_LOAD>(drsrc, row_base, lane_off, lane, stage, mine);
         } else {
           uint4 mine[6];
           __builtin_memcpy(mine, t, sizeof(mine));
-          wave_store_units<uint4, 6>(drsrc, row_base, lane_off, lane, stage, mine);
+          wave_store_units<uint4, 6, MI_ST_LOAD>(drsrc, row_base, lane_off, lane, stage, mine);
         }
       }
       if constexpr (BOUNDS) {
@@ -726,18 +734,18 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
             linear_n<24>(o, lo2, inv2, p.gamma_inv, out_scale);                     // tonemap.py:154
             const uint32_t row_base = (uint32_t)row * out_pitch + band_base;
             switch (p.out_dtype) {
-              case MI_U8: wave_store_row_t<uint8_t>(drsrc, row_base, lane_off, lane, stage, o); break;
-              case MI_U16: wave_store_row_t<uint16_t>(drsrc, row_base, lane_off, lane, stage, o); break;
+              case MI_U8: wave_store_row_t<uint8_t, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, o); break;
+              case MI_U16: wave_store_row_t<uint16_t, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, o); break;
               case MI_F16: {                                // pairs leave through v_cvt_pk_f16_f32 (half the conversions)
                 uint32_t pk2[12];
 #pragma unroll
                 for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk2[j]) : "v"(o[2 * j]), "v"(o[2 * j + 1]));
                 uint4 mine[3];
                 __builtin_memcpy(mine, pk2, sizeof(mine));
-                wave_store_units<uint4, 3>(drsrc, row_base, lane_off, lane, stage, mine);
+                wave_store_units<uint4, 3, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, mine);
                 break;
               }
-              default: wave_store_row_t<float>(drsrc, row_base, lane_off, lane, stage, o); break;
+              default: wave_store_row_t<float, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, o); break;
             }
           }
         };
