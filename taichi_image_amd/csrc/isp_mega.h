@@ -29,7 +29,15 @@
 // write-through, atomic add; poll the counters, then load the partials) two of the four dependent memory round trips
 // after the last arrival are gone.  Every block must be resident at once: the host launches at most 2 blocks per CU
 // and refuses larger frames (they take the multi-pass chain); a bounded poll turns a missing peer into an error flag
-// in the workspace instead of a hang.
+// in the workspace (and a store to the device's host-mapped mailbox) instead of a hang.
+//
+// ASSUMPTION the barrier rests on: a 16-byte sc1 store to a 16-byte aligned address is observed WHOLE by a 16-byte sc1
+// load of that address - a poller never sees the new tag next to old values.  The ISA manual does not promise it; the
+// evidence is empirical (scripts/wf_soak.py: 2 000 000 frames compared bit for bit, tests/test_gpu_fullsize.py::
+// test_whole_frame_kernel_is_deterministic).  A torn record would show as a frame that differs from its first run.
+//
+// Round 3: ONE launch walks through a batch of frames (MBatch): the grid stays resident, the counters in LDS run on over
+// the frames, a wave that has stored its rows of frame f goes straight on to frame f + 1.
 #pragma once
 #include "isp_stream.h"
 
@@ -192,7 +200,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   // 4.6 us instead of 1); two requests per wave and round do not.  Four polls in flight, a new one every 512 cycles.
   // Whichever blocks post last are deliberately NOT waited for here: stage 1 asks for whatever is still missing every
   // round, so a straggler's record is seen one round trip after it lands.
-  {
+  if (m.spin_limit > 1) {                             // (a budget of 1 - the fault test - polls at once)
     const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
     const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + 12u : INVALID_OFF;
     const bool idle = !(lane < 2 && watch >= 0);
@@ -236,16 +244,19 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       for (int c = 0; c < NCH; ++c) { have[u][c] = have[u][c] || v[u][c].w == tag; all = all && have[u][c]; }
     return __builtin_amdgcn_ballot_w64(!all);
   };
-  unsigned long long missing = m.l2_first ? round(std::integral_constant<int, 1>{}) : ~0ull;
+  unsigned long long missing = m.l2_first && m.spin_limit > 1 ? round(std::integral_constant<int, 1>{}) : ~0ull;
   while (missing != 0) {
-    // (the budget is checked BEFORE the next round: a budget of 1 - tests/ - gives up on the first missing record)
-    if (++spins > m.spin_limit) {                     // a peer is not resident: give up loudly instead of hanging
+    // The budget is checked BEFORE a round.  A budget of 1 (tests/: mi_isp_whole_frame_set_poll_limit(1)) therefore means
+    // "one round, straight after the wave's own post, no watch stage": the first block to arrive cannot find the others'
+    // records there, so at least one block reports the fault - deterministically.
+    if (spins >= m.spin_limit) {                      // a peer is not resident: give up loudly instead of hanging
       if (lane == 0) {
         __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (m.mailbox) __hip_atomic_store(m.mailbox, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       break;
     }
+    ++spins;
     // many records missing: the phase is still running elsewhere, poll rarely; few: the last arrivals, poll at once
     const unsigned naps = spins > 1 && __builtin_popcountll(missing) > 16 ? 4u * m.poll_sleep + 1u : m.poll_sleep;
     for (unsigned z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
