@@ -48,15 +48,23 @@ struct ReinhardK {
 // CA0 (color_adapt == 0): adapt_color == gray and mean3 is the same for the three channels, so
 // the three channels share one pow.  A template parameter, not a per-pixel test: the callers branch
 // once per row of pixels (a scalar branch), keeping the pixel code straight-line.
+// the adaptation term the three channels of a pixel share when color_adapt == 0 (tonemap.py:120-129)
+MI_DEV float reinhard_adapt_ca0(const float (&t)[3], const ReinhardK& k) {
+  const float g = rgb_gray(t[0], t[1], t[2]);
+  const float am = k.mean3[0] + k.la * (g - k.mean3[0]);
+  return hw_pow(k.ei * am, k.map_key);
+}
+// one channel: t / (ad + t)
+MI_DEV float reinhard_map(float t, float ad) { return t * hw_rcp(ad + t); }
+
 template <bool CA0>
 MI_DEV void reinhard_px(const float (&t)[3], const ReinhardK& k, float (&out)[3]) {
-  const float g = rgb_gray(t[0], t[1], t[2]);
   if constexpr (CA0) {
-    const float am = k.mean3[0] + k.la * (g - k.mean3[0]);
-    const float ad = hw_pow(k.ei * am, k.map_key);
+    const float ad = reinhard_adapt_ca0(t, k);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = t[c] * hw_rcp(ad + t[c]);
+    for (int c = 0; c < 3; ++c) out[c] = reinhard_map(t[c], ad);
   } else {
+    const float g = rgb_gray(t[0], t[1], t[2]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float ac = g + k.ca * (t[c] - g);

@@ -744,21 +744,45 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   // the LDS rows alone.
   vmin = __builtin_inff(); vmax = -__builtin_inff();
   float qr_[NR][24];
+  // An LDS row's mapped values are not kept, only their bounds are wanted - and with color_adapt == 0 the three channels
+  // of a pixel share the adaptation term ad, q = t / (ad + t) is increasing in t, so the pixel's smallest and largest
+  // mapped value are those of its smallest and largest channel: two reciprocals per pixel instead of three (the value
+  // is the same instruction sequence on the same operand; where the hardware reciprocal is not monotone to the last
+  // bit the bound can differ from the three-channel one by an ulp - the scalars' contract is 1e-4).
+  auto tone_bounds_row = [&](auto unit_c, const float (&t)[24]) {
+    constexpr bool UNIT = decltype(unit_c)::value;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float x[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm01(t[3 * k + ch], lo, inv);
+      const float ad = reinhard_adapt_ca0(x, rk);       // (the very function phase D evaluates again)
+      const float xmin = fminf(x[0], fminf(x[1], x[2])), xmax = fmaxf(x[0], fmaxf(x[1], x[2]));
+      vmin = fminf(vmin, reinhard_map(xmin, ad));
+      vmax = fmaxf(vmax, reinhard_map(xmax, ad));
+    }
+  };
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
     if constexpr (RR >= NL) fresh(qr_[RR - NL]);
     if (r_begin + RR < r_end) {
-      float t[24], q[24];
+      float t[24];
       resident(rrc, t);
-      dispatch([&](auto unit_c, auto ca0_c) { tone_row(unit_c, ca0_c, t, q); });
+      if (RR < NL && ca0) {                            // (wave-uniform)
+        if (unit) tone_bounds_row(std::true_type{}, t);
+        else tone_bounds_row(std::false_type{}, t);
+      } else {
+        float q[24];
+        dispatch([&](auto unit_c, auto ca0_c) { tone_row(unit_c, ca0_c, t, q); });
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        vmin = fminf(vmin, fminf(q[3 * k], fminf(q[3 * k + 1], q[3 * k + 2])));
-        vmax = fmaxf(vmax, fmaxf(q[3 * k], fmaxf(q[3 * k + 1], q[3 * k + 2])));
-      }
-      if constexpr (RR >= NL) {
+        for (int k = 0; k < 8; ++k) {
+          vmin = fminf(vmin, fminf(q[3 * k], fminf(q[3 * k + 1], q[3 * k + 2])));
+          vmax = fmaxf(vmax, fmaxf(q[3 * k], fmaxf(q[3 * k + 1], q[3 * k + 2])));
+        }
+        if constexpr (RR >= NL) {
 #pragma unroll
-        for (int j = 0; j < 24; ++j) qr_[RR - NL][j] = q[j];
+          for (int j = 0; j < 24; ++j) qr_[RR - NL][j] = q[j];
+        }
       }
     }
   });
