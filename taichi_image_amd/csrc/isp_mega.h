@@ -323,7 +323,11 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
         for (int k = 0; k < (NV == 1 ? 1 : 5); ++k) tot[NMM + k] = ((fl.sum[0][k] + fl.sum[1][k]) + fl.sum[2][k]) + fl.sum[3][k];
       }
       ew::FinArgs fa = {};
-      fa.fp = sh_fp; fa.n_px = a.n_px; fa.intensity = a.intensity; fa.la = a.t.la; fa.ca = a.t.ca;
+      // (laundered: what the finalize derives from these alone - 1 / n, exp(-intensity) - is loop-invariant, and hoisted out
+      // of the frame loop it is spilled at the kernel's entry and reloaded here, in every block, for every frame)
+      float npx = a.n_px, intensity = a.intensity;
+      asm volatile("" : "+s"(npx), "+s"(intensity));
+      fa.fp = sh_fp; fa.n_px = npx; fa.intensity = intensity; fa.la = a.t.la; fa.ca = a.t.ca;
       fa.bounds_post = a.bounds_post;
       if constexpr (NV == 9) {
         ew::finalize_scalars_fast(ew::FIN_BOUNDS, fa, tot);
@@ -340,7 +344,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
         // rounding: ~1e-7 relative, the contract of these scalars is 1e-4); only the sum of logarithms needs the pixels
         // (phase B: tot[0]).  fp32 throughout: the sums are fp32 sums of 12.6 M values to begin with (~1e-7 relative),
         // and n * lo takes away at most the part of them that the image's minimum accounts for.
-        const float lo = sh_fp[FP_LO], inv = sh_fp[FP_INV], nlo = a.n_px * sh_fp[FP_LO];
+        const float lo = sh_fp[FP_LO], inv = sh_fp[FP_INV], nlo = npx * sh_fp[FP_LO];
         float t7[7];
         t7[0] = (fl.keep[0] - lo) * inv; t7[1] = (fl.keep[1] - lo) * inv;
         t7[2] = tot[0];
