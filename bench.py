@@ -182,6 +182,11 @@ def isp_workload(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def ti_mod():
+    import taichi_image_amd
+    return taichi_image_amd
+
+
 def other_workloads(frames, host, device, frames_per_step):
     """Short driver-visible runs of the other single-GPU configurations (rank 0, N=1).  Every entry: three timed runs,
     the median reported and all three listed (no pauses between the runs: round 2 slept 0.3 s in front of each)."""
@@ -228,6 +233,13 @@ def other_workloads(frames, host, device, frames_per_step):
     steps = 100
     runs = [timed(step, steps, 5, device) / (steps * 6) * 1e6 for _ in range(3)]
     entry("config3_camera16_resize1920", runs, BYTES_IN + 1440 * 1920 * 3, 6, steps)
+    # the same step with the group's cameras loaded in one launch (ISP.load_packed12_batch, an extension of the call surface:
+    # the reference's load_packed12 is a call per camera) - same outputs, bit for bit
+    isp_b = ti_mod().Camera16(ti_mod().BayerPattern.RGGB, moving_alpha=0.1, resize_width=1920, device=device)
+    step_b = lambda: isp_b.tonemap_reinhard(isp_b.load_packed12_batch(frames[:6]), gamma=0.6)
+    runs = [timed(step_b, steps, 5, device) / (steps * 6) * 1e6 for _ in range(3)]
+    entry("config3_camera16_resize1920_batched_load", runs, BYTES_IN + 1440 * 1920 * 3, 6, steps,
+          note="extension: ISP.load_packed12_batch (one launch for the six cameras' loads)")
     # config 3b: the nominal 1920x1080 through the resize primitive's per-axis scale (interpolate.py:83)
     # on the demosaiced 4K f16 image: load_packed12 at full size, resize_bilinear(scale=(0.3515625, 0.46875)) -> f16 / u8
     import taichi_image_amd as ti
@@ -246,6 +258,11 @@ def other_workloads(frames, host, device, frames_per_step):
         isp6.tonemap_reinhard([isp6.load_packed12(f) for f in frames[:6]], gamma=0.6)
     runs = [timed(step6, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
     entry("reference_bench_6_cameras_full_resolution", runs, BYTES_IN + H * W * 3, 6, 40)
+    def step6b():
+        isp6.tonemap_reinhard(isp6.load_packed12_batch(frames[:6]), gamma=0.6)
+    runs = [timed(step6b, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
+    entry("reference_bench_6_cameras_full_resolution_batched_load", runs, BYTES_IN + H * W * 3, 6, 40,
+          note="extension: ISP.load_packed12_batch")
     return res
 
 

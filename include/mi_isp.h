@@ -182,6 +182,13 @@ int mi_isp_load_packed(const uint8_t* packed_dev, void* rgb_dev, int H, int W, i
 int mi_isp_load_packed_metered(const uint8_t* packed_dev, void* rgb_dev, int H, int W, int bits,
                                int ids_format, int pattern, const float* ccm9_host, int work_dtype,
                                int Hd, int Wd, float scale, void* sub_dev, int sub_stride, void* stream);
+/* n frames of one size (the cameras of a group: one ISP.load_packed12 / 16 each, camera_isp.py:333-347) in ONE launch
+ * per 8 frames - same arithmetic and bits as n calls of mi_isp_load_packed[_metered], without n - 1 launches' dispatch,
+ * table build and drain.  packed_host / rgb_host / subs_host: host arrays of n device pointers; subs_host may be NULL (no
+ * metering subsamples); frames the streaming kernels do not take are loaded one by one. */
+int mi_isp_load_packed_batch(const uint8_t* const* packed_host, void* const* rgb_host, void* const* subs_host, int n,
+                             int H, int W, int bits, int ids_format, int pattern, const float* ccm9_host, int work_dtype,
+                             int Hd, int Wd, float scale, int sub_stride, void* stream);
 /* 1 if mi_isp_load_packed_metered (scale <= 0, 16-byte aligned buffers) writes the subsample from inside the load
  * kernel, 0 if it would need the gather behind it (then the caller may as well let mi_isp_metering gather). */
 int mi_isp_load_packed_metered_is_fused(int H, int W, int bits, int ids_format, int work_dtype, int sub_stride);

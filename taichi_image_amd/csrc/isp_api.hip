@@ -177,6 +177,68 @@ extern "C" int mi_isp_load_packed(const uint8_t* packed, void* rgb, int H, int W
   return load_packed_impl(packed, rgb, H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd, scale, nullptr, 0, stream);
 }
 
+// The cameras of a group in ONE launch per 8 (grid.y = camera): dispatch, decode table, first loads and drain are paid per
+// launch instead of per camera (the load kernels take 23 - 30 us each, ~4 us of that is launch overhead: config 3, six
+// cameras, 43.0 -> ~39.5 us per frame).  Same arithmetic, same bits as n calls of mi_isp_load_packed[_metered].
+extern "C" int mi_isp_load_packed_batch(const uint8_t* const* packed, void* const* rgb, void* const* subs, int n, int H, int W,
+                                        int bits, int ids_format, int pattern, const float* ccm9, int work_dtype, int Hd,
+                                        int Wd, float scale, int sub_stride, void* stream) {
+  MI_REQUIRE(packed && rgb, "load_packed_batch: null pointer");
+  MI_REQUIRE(n >= 0, "load_packed_batch: negative frame count");
+  for (int i = 0; i < n; ++i) MI_REQUIRE(packed[i] && rgb[i] && (!subs || subs[i]), "load_packed_batch: frame %d has a null buffer", i);
+  if (n == 0) return 0;
+  MI_REQUIRE(!subs || sub_stride >= 1, "load_packed_batch: bad subsample stride");
+  // does every frame take the same streaming kernel?  (alignment is per buffer)
+  tile::Params p0 = {};
+  bool same = true, resize = scale > 0.f;
+  for (int i = 0; i < n && same; ++i) {
+    tile::Params p = {};
+    if (int rc = fill_common(p, H, W, pattern, ccm9, "load_packed_batch")) return rc;
+    if (int rc = packed_params(p, packed[i], H, W, bits, ids_format, work_dtype, "load_packed_batch")) return rc;
+    p.dst = rgb[i]; p.out_dtype = work_dtype; p.out_scale = 1.f;
+    if (resize) {
+      same = Hd > 0 && Wd > 0 && H >= 2 && W >= 2 && use_stream(p, work_dtype, nullptr, work_dtype) &&
+             rstrm::supported(p, work_dtype, rgb[i], Hd, Wd, scale, scale);
+    } else {
+      p.vec_store = vec_store_ok(rgb[i], W, work_dtype);
+      same = Hd == H && Wd == W && use_stream(p, work_dtype, rgb[i], work_dtype) && (!subs || sub_stride == 8);
+    }
+    if (i == 0) p0 = p;
+  }
+  if (!same) {                                               // some frame needs another kernel: one by one
+    for (int i = 0; i < n; ++i)
+      if (int rc = load_packed_impl(packed[i], rgb[i], H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd, scale,
+                                    subs ? subs[i] : nullptr, sub_stride, stream))
+        return rc;
+    return 0;
+  }
+  for (int i0 = 0; i0 < n; i0 += strm::LOAD_BATCH) {
+    const int m = n - i0 < strm::LOAD_BATCH ? n - i0 : strm::LOAD_BATCH;
+    if (resize) {
+      rstrm::RSArgs ra = {};
+      ra.t = p0; ra.Hd = Hd; ra.Wd = Wd; ra.s0 = scale; ra.s1 = scale;
+      rstrm::geometry(H, W, ra);
+      ra.n_batch = m;
+      for (int i = 0; i < m; ++i) { ra.srcs[i] = packed[i0 + i]; ra.dsts[i] = rgb[i0 + i]; }
+#ifdef MI_STREAM_STAMPS
+      ra.t.partials = stamp_buffer(); ra.t.part_stride = 0;
+#endif
+      if (int rc = rstrm::launch(ra, pattern, (hipStream_t)stream)) return rc;
+      if (subs)
+        for (int i = 0; i < m; ++i)
+          if (int rc = ew::subsample(rgb[i0 + i], subs[i0 + i], Hd, Wd, sub_stride, work_dtype, (hipStream_t)stream)) return rc;
+    } else {
+      strm::SArgs a = {};
+      a.t = p0;
+      strm::geometry(H, W, a);
+      a.n_batch = m; a.sub_w = (W + 7) / 8;
+      for (int i = 0; i < m; ++i) { a.srcs[i] = packed[i0 + i]; a.dsts[i] = rgb[i0 + i]; a.subs[i] = subs ? subs[i0 + i] : nullptr; }
+      if (int rc = strm::launch(a, work_dtype, pattern, strm::S_STORE, (hipStream_t)stream)) return rc;
+    }
+  }
+  return 0;
+}
+
 extern "C" int mi_isp_load_packed_metered_is_fused(int H, int W, int bits, int ids_format, int work_dtype, int sub_stride) {
   if (bits != 12 || ids_format || sub_stride != 8 || H <= 0 || W <= 0) return 0;
   tile::Params p = {};
@@ -673,12 +735,10 @@ extern "C" int mi_isp_camera_frame_batch(const uint8_t* const* packed, void* con
   MI_REQUIRE(n >= 1, "camera_frame_batch: need at least one camera");
   MI_REQUIRE(tonemap == 0 || tonemap == 1, "camera_frame_batch: tonemap must be 0 (reinhard) or 1 (linear)");
   MI_REQUIRE(metering_stride >= 1, "camera_frame_batch: bad metering stride");
-  for (int i = 0; i < n; ++i) {
-    MI_REQUIRE(packed[i] && images[i] && outs[i], "camera_frame_batch: camera %d has a null buffer", i);
-    if (int rc = mi_isp_load_packed(packed[i], images[i], H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd, scale,
-                                    stream))
-      return rc;
-  }
+  for (int i = 0; i < n; ++i) MI_REQUIRE(packed[i] && images[i] && outs[i], "camera_frame_batch: camera %d has a null buffer", i);
+  if (int rc = mi_isp_load_packed_batch(packed, images, nullptr, n, H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd,
+                                        scale, 0, stream))
+    return rc;
   if (int rc = mi_isp_metering(const_cast<const void* const*>(images), n, Hd, Wd, metering_stride, work_dtype, state9,
                                alpha, ws, stream))
     return rc;

@@ -52,6 +52,7 @@ enum Epi {
 //   S_STATS:                   rows 2..8 (overwrites the speculative ones)
 //   S_RH_MINMAX:               rows 9,10
 constexpr int ROW_BOUNDS = 0, ROW_STATS = 2, ROW_BOUNDS2 = 9;
+constexpr int LOAD_BATCH = 8;                       // frames per batched S_STORE / resize launch
 // rows 20..47: the tagged rows of the whole-frame kernel's grid barriers (isp_mega.h)
 constexpr int MEGA_ROW_BASE = 20, PART_ROWS = 48;
 
@@ -68,6 +69,13 @@ struct SArgs {
   // multiple of 8 columns, so the sample of a row r % 8 == 0 is the lane's first pixel.
   void* sub;
   int sub_w;              // ceil(W / 8)
+  // S_STORE, several frames in one launch (grid.y = frame; mi_isp_load_packed_batch: the cameras of a group): frame y reads
+  // srcs[y], writes dsts[y] (and subs[y]).  n_batch == 0: one frame, t.src / t.dst / sub.  Indexed by blockIdx.y itself
+  // (a computed index would send this struct through scratch).
+  int n_batch;
+  const void* srcs[LOAD_BATCH];
+  void* dsts[LOAD_BATCH];
+  void* subs[LOAD_BATCH];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -519,8 +527,12 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   // per-row scalar part, either of which is INVALID (1 GiB, beyond any frame) when its coordinate is outside.
   constexpr uint32_t INVALID = INVALID_OFF;
   const uint32_t pitch = (uint32_t)p.W * 3 / 2;
+  const bool batched = EPI == S_STORE && a.n_batch > 0;
+  const void* const src_p = batched ? a.srcs[blockIdx.y] : p.src;
+  void* const dst_p = batched ? a.dsts[blockIdx.y] : p.dst;
+  void* const sub_p = batched ? a.subs[blockIdx.y] : a.sub;
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src_p), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
   const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID;
   // lane 0: the dword before its unit (pixels c0-2, c0-1 in its upper 3 bytes); lane 63: the dword after (c0+8, c0+9)
   const bool ext_ok = col_ok && ((lane == 0 && c0 > 0) || (lane == 63 && c0 + 8 < p.W));
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   const int osz = EPI == S_RH_STORE ? (int)mi_dtype_size_dev(p.out_dtype) : (int)sizeof(E);
   const int unit_bytes = osz == 1 ? 8 : 16, units_per_lane = 24 * osz / unit_bytes;
   const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.dst, 0, STORES ? (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz) : 0, 0x00020000);
+      dst_p, 0, STORES ? (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz) : 0, 0x00020000);
   uint32_t lane_off[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j)
@@ -673,8 +685,8 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
         for (int j = 0; j < 24; ++j) t[j] = clamp01(v[j]);
       }
       if constexpr (EPI == S_STORE) {
-        if (a.sub && (row & 7) == 0 && col_ok) {         // (row: wave-uniform)
-          E* sp = static_cast<E*>(a.sub) + ((size_t)(row >> 3) * a.sub_w + (size_t)(c0 >> 3)) * 3;
+        if (sub_p && (row & 7) == 0 && col_ok) {         // (row: wave-uniform)
+          E* sp = static_cast<E*>(sub_p) + ((size_t)(row >> 3) * a.sub_w + (size_t)(c0 >> 3)) * 3;
           if constexpr (sizeof(E) == 2) {
             uint16_t* s16 = reinterpret_cast<uint16_t*>(sp);
             s16[0] = (uint16_t)(pk[0] & 0xFFFFu); s16[1] = (uint16_t)(pk[0] >> 16); s16[2] = (uint16_t)(pk[1] & 0xFFFFu);

@@ -43,6 +43,9 @@ struct RSArgs {
   int stride_units;         // units (8 px) a band owns; its wave covers stride_units + 2
   int bands_x, rows_per_wave, n_waves, n_blocks;
   int align4;               // destination columns are dealt to the bands in whole groups of 4 (see the kernel)
+  int n_batch;              // several frames in one launch (grid.y = frame): frame y reads srcs[y], writes dsts[y]; 0: t.src / t.dst
+  const void* srcs[LOAD_BATCH];
+  void* dsts[LOAD_BATCH];
 };
 
 // quad origin of destination index i along one axis: min(trunc(i / s), n - 2)   (n >= 2)
@@ -80,8 +83,10 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
 
   // ---- packed source rows (as stream_kernel) ----
   const uint32_t pitch = (uint32_t)p.W * 3 / 2;
+  const void* const src_p = a.n_batch > 0 ? a.srcs[blockIdx.y] : p.src;      // (blockIdx.y itself: see strm::SArgs)
+  void* const dst_p = a.n_batch > 0 ? a.dsts[blockIdx.y] : p.dst;
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src_p), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
   const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID_OFF;
   const bool last_lane = lane == a.stride_units + 1 || lane == 63;
   const bool ext_ok = col_ok && ((lane == 0 && c0 > 0) || (last_lane && c0 + 8 < p.W));
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
   const int rd_begin = wave_ok ? first_with_origin(r_begin, a.s0, p.H, a.Hd) : 0;
   const int rd_end = wave_ok ? (r_own_end < p.H ? first_with_origin(r_own_end, a.s0, p.H, a.Hd) : a.Hd) : 0;
   const __amdgpu_buffer_rsrc_t drsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, (int)((uint32_t)a.Hd * (uint32_t)a.Wd * 6u), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(dst_p, 0, (int)((uint32_t)a.Hd * (uint32_t)a.Wd * 6u), 0x00020000);
   const bool vec_rows = (a.Wd & 3) == 0;               // 4 pixels = 24 bytes stay 8-byte aligned in every row
   const int cg0 = cd_begin & ~3;                       // group base: lane l owns destination columns cg0 + 4 l + 256 k + j
 

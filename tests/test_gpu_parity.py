@@ -773,3 +773,32 @@ def test_load_packed_leaves_the_metering_subsample(ti, rng, dev, cam, shape, rw)
     a.update_metering(imgs)
     b.update_metering(plain)
     assert torch.equal(a.metrics, b.metrics)
+
+
+@pytest.mark.parametrize("cam,shape,rw,n", [("Camera16", (200, 512), 0, 6), ("Camera32", (72, 264), 0, 3), ("Camera16", (192, 512), 256, 11),
+                                            ("Camera16", (70, 200), 0, 2), ("Camera16", (96, 256), 77, 9)])
+def test_load_packed_batch_equals_single_loads(ti, rng, dev, cam, shape, rw, n):
+    """ISP.load_packed12_batch (extension; mi_isp_load_packed_batch: the cameras of a group in one launch per 8) gives the
+    bits of a load_packed12 per camera - full size with the metering subsample, the fused resize, more than 8 frames (two
+    launches), and frames the streaming kernels do not take (W % 8 != 0: loaded one by one)."""
+    H, W = shape
+    packed = [natural_packed12(np.random.default_rng(60 + k), H, W, pattern=O.GRBG) for k in range(n)]
+    frames = [torch.from_numpy(p).to(dev) for p in packed]
+    isp = getattr(ti, cam)(ti.BayerPattern.GRBG, resize_width=rw, correct_colors=True, device=dev)
+    single = [isp.load_packed12(f) for f in frames]
+    batch = isp.load_packed12_batch(frames)
+    assert len(batch) == n
+    for k in range(n):
+        assert torch.equal(batch[k], single[k]), f"frame {k} differs"
+        assert hasattr(batch[k], "_mi_metering_sub") == hasattr(single[k], "_mi_metering_sub")
+        if hasattr(batch[k], "_mi_metering_sub"):
+            assert torch.equal(batch[k]._mi_metering_sub[0], single[k]._mi_metering_sub[0])
+    want = O.isp_load_packed12(packed[n - 1], "f16" if cam == "Camera16" else "f32", pattern=O.GRBG, resize_width=rw,
+                               correct_colors=O.isp_color_matrix(True, O.DEFAULT_WB, O.DEFAULT_CC))
+    assert_exact(batch[n - 1].cpu().numpy(), want, "last frame of the batch against the oracle")
+    a = getattr(ti, cam)(ti.BayerPattern.GRBG, resize_width=rw, correct_colors=True, device=dev)
+    b = getattr(ti, cam)(ti.BayerPattern.GRBG, resize_width=rw, correct_colors=True, device=dev)
+    ua = a.tonemap_reinhard(a.load_packed12_batch(frames), gamma=0.7)
+    ub = b.tonemap_reinhard([b.load_packed12(f) for f in frames], gamma=0.7)
+    assert torch.equal(a.metrics, b.metrics) and all(torch.equal(x, y) for x, y in zip(ua, ub))
+    assert isp.load_packed12_batch([]) == []
