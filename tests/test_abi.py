@@ -53,6 +53,24 @@ def test_argument_validation_reports_errors():
     assert L.mi_isp_transform(p, p, 4, 8, 0, 7, None) != 0           # transverse on non-square
     with pytest.raises(RuntimeError, match="libmi355_isp"):
         _native.check(L.mi_isp_resize_bilinear(p, p, 4, 4, 2, 2, 0.0, 0.5, 2, 2, None))
+    # the round-3 entry points validate before they touch a device
+    P = ctypes.c_void_p
+    one = (P * 1)(p)
+    assert L.mi_isp_pipeline12_reinhard_whole_frame_batch(None, None, 1, 64, 512, 0, 0, None, 2, 1.0, 1.0, 1.0, 0.0, None, None) != 0
+    assert b"null" in L.mi_isp_last_error()
+    assert L.mi_isp_pipeline12_reinhard_whole_frame_batch(one, one, 0, 64, 512, 0, 0, None, 2, 1.0, 1.0, 1.0, 0.0, p, None) != 0
+    assert b"at least one frame" in L.mi_isp_last_error()
+    assert L.mi_isp_load_packed_batch(None, None, None, 1, 64, 512, 12, 0, 0, None, 2, 64, 512, 0.0, 8, None) != 0
+    assert L.mi_isp_load_packed_batch(one, one, None, -1, 64, 512, 12, 0, 0, None, 2, 64, 512, 0.0, 8, None) != 0
+    assert L.mi_isp_load_packed_batch(one, one, None, 0, 64, 512, 12, 0, 0, None, 2, 64, 512, 0.0, 8, None) == 0      # nothing to do
+    assert L.mi_isp_load_packed_metered(p, p, 64, 512, 12, 0, 0, None, 2, 64, 512, 0.0, None, 8, None) != 0           # no subsample buffer
+    nbad = ctypes.c_int(0)
+    assert L.mi_isp_workspace_check(None, 1, 64, 512, None, ctypes.byref(nbad), None) != 0
+    assert L.mi_isp_workspace_check(p, 1, 0, 0, None, ctypes.byref(nbad), None) != 0
+    assert L.mi_isp_load_packed_metered_is_fused(3072, 4096, 12, 0, 2, 8) == 1
+    assert L.mi_isp_load_packed_metered_is_fused(3072, 4096, 12, 0, 2, 4) == 0 and L.mi_isp_load_packed_metered_is_fused(70, 204, 12, 0, 2, 8) == 0
+    assert L.mi_isp_load_packed_metered_is_fused(3072, 4096, 16, 0, 2, 8) == 0 and L.mi_isp_load_packed_metered_is_fused(3072, 4096, 12, 1, 2, 8) == 0
+    assert L.mi_isp_whole_frame_set_poll_limit(0) == 0
 
 
 def test_no_cpu_fallback():
