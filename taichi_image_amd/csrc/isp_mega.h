@@ -68,6 +68,19 @@ using namespace strm;
 #endif
 #endif
 
+#ifndef MI_MEGA_PRIO                     /* how the two waves of a SIMD share its issue slots: prio_turn() */
+#define MI_MEGA_PRIO 1
+#endif
+#ifndef MI_MEGA_PRIO_D                   /* turns in phase D too: measured, nothing (46.0 either way; non-unit frames 54.5 against 54.0) */
+#define MI_MEGA_PRIO_D 0
+#endif
+#ifndef MI_MEGA_PRIO_TURN_SHIFT
+#define MI_MEGA_PRIO_TURN_SHIFT 0
+#endif
+#ifndef MI_MEGA_PRIO_SHIFT
+#define MI_MEGA_PRIO_SHIFT 11            /* slices of 2048 cycles (~1 us) */
+#endif
+
 constexpr int ROWS = 12;             // rows per wave
 constexpr int NL = 5;                // of which live in LDS ...
 constexpr int NR = ROWS - NL;        // ... and in registers
@@ -414,6 +427,28 @@ template <class T, int N> MI_DEV void fresh(T (&x)[N]) {
   for (int i = 0; i < N; ++i) x[i] = __builtin_nondeterministic_value(x[i]);
 }
 
+// Issue priority of the wave.  The two blocks of a CU put one wave each on every SIMD, and between two waves that are
+// both ready the hardware picks the OLDER one - the block that was dispatched first.  Measured (scripts/wf_skew.py): the
+// waves of blocks 0 .. n/2 - 1 end phase A 3.6 us before those of blocks n/2 .. n - 1, frame after frame (correlation
+// 0.91), then idle at the barrier while their SIMD runs the other wave alone - at half its issue rate.  The waves
+// therefore swap priority every row pair of phase A and every row of phase C: `turn` counts them, `younger` is the
+// block's half; whoever has the turn wins the ties.  46.9 -> 46.0 us per frame; the halves then end phase A 0.7 us apart
+// (3.8 before).  Also measured: slices of the CU's clock instead of turns (MI_MEGA_PRIO 3: 46.0 with 8192-cycle slices,
+// 46.4 with 2048, 47.8 with 32768), the younger block always first (MI_MEGA_PRIO 2: the asymmetry flips).
+MI_DEV void prio_turn(int turn, bool younger) {
+#if MI_MEGA_PRIO == 1
+  if ((((turn >> MI_MEGA_PRIO_TURN_SHIFT) & 1) != 0) == younger) asm volatile("s_setprio 1");
+  else asm volatile("s_setprio 0");
+#elif MI_MEGA_PRIO == 2              /* measurement: the younger block always wins */
+  if (younger) asm volatile("s_setprio 3");
+  else asm volatile("s_setprio 0");
+#elif MI_MEGA_PRIO == 3              /* time slices of the CU's own clock: both waves of a SIMD read the same counter */
+  const unsigned now = (unsigned)__builtin_readcyclecounter();
+  if ((((now >> MI_MEGA_PRIO_SHIFT) & 1u) != 0) == younger) asm volatile("s_setprio 3");
+  else asm volatile("s_setprio 0");
+#endif
+}
+
 // bounds of a packed f16 row: four values per instruction (gfx950: v_pk_minimum3_f16 / v_pk_maximum3_f16; the values are
 // clamped and finite, so the NaN rule of the IEEE-2019 minimum does not come into play)
 MI_DEV void pk_bounds_row(const uint32_t (&pk)[12], uint32_t& mn, uint32_t& mx) {
@@ -431,6 +466,7 @@ MI_DEV float pk_hi(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return
 #ifndef MI_MEGA_D_ORDER
 #define MI_MEGA_D_ORDER 1
 #endif
+
 #ifndef MI_MEGA_PREFETCH_AT
 #define MI_MEGA_PREFETCH_AT 3            /* register rows first: behind LDS row 3 */
 #endif
@@ -481,7 +517,11 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     Geo G;
     G.lane = tid & 63;
     G.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MI_MEGA_TEST_PERMUTE          /* measurement only: even dispatch indices take the top half of the image, odd ones the bottom */
+    G.g = ((bid & 1) * (a.n_blocks >> 1) + (bid >> 1)) * WAVES + G.wave;
+#else
     G.g = bid * WAVES + G.wave;
+#endif
     G.wave_ok = G.g < a.n_waves;
     const int by = G.g / a.bands_x;
     G.bx = G.g - by * a.bands_x;
@@ -534,6 +574,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   asm volatile("" : "+v"(tid_), "+s"(bid_));
   const Geo G = geo(tid_, bid_);
   const int lane = G.lane, wave = G.wave, g = G.g, bx = G.bx, r_begin = G.r_begin, r_end = G.r_end, active_lanes = G.active_lanes;
+  const bool younger = bid_ >= (a.n_blocks >> 1);       // the second of the two blocks of its CU (dispatch order)
   const bool wave_ok = G.wave_ok, col_ok = G.col_ok, is_left = G.is_left, is_right = G.is_right, any_left = G.any_left,
              any_right = G.any_right;
   // output rows leave through a buffer resource (wave_store_units): unit j * 64 + lane of the band's row
@@ -578,6 +619,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   static_for<0, ROWS / 2>([&](auto ibc) {
     constexpr int IB = decltype(ibc)::value, PH = IB % 3;
     const int r = r_begin + 2 * IB;
+    prio_turn(IB, younger);
     decode_row(raw[IB % 2][0], lut, lane, win[(2 * PH + 4) % 6]);
     decode_row(raw[IB % 2][1], lut, lane, win[(2 * PH + 5) % 6]);
     if constexpr (IB + 2 < ROWS / 2) {
@@ -596,6 +638,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       static_for<0, 2>([&](auto ic) {
         constexpr int I = decltype(ic)::value, RR = 2 * IB + I;
         const int row = r + I;
+        if constexpr (I == 1) prio_turn(IB, younger);
         float v[24];
         accumulate_row<PR, PC, I, true>(w6, wq, v);
         if (MI_CENSUS(row < 2 || row >= p.H - 2, false)) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
@@ -769,6 +812,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
     if constexpr (RR >= NL) fresh(qr_[RR - NL]);
+    prio_turn(RR, younger);
     if (r_begin + RR < r_end) {
       float t[24];
       resident(rrc, t);
@@ -834,6 +878,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       io.dst, 0, (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz), 0x00020000);
   auto finish_row = [&](auto rrc, float (&q)[24]) {
     constexpr int RR = decltype(rrc)::value;
+#if MI_MEGA_PRIO_D
+    prio_turn(RR, younger);
+#endif
     linear_n<24>(q, lo2, inv2, p.gamma_inv, out_scale);
     // staging: the LDS slot of a row that has been consumed (its own, or row 0's for the register rows)
     uint4* stage = xl[wave][RR < NL ? RR : 0];
