@@ -74,6 +74,15 @@ using namespace strm;
 #ifndef MI_MEGA_PRIO_D                   /* turns in phase D too: measured, nothing (46.0 either way; non-unit frames 54.5 against 54.0) */
 #define MI_MEGA_PRIO_D 0
 #endif
+#ifndef MI_MEGA_PRIO_ROWS
+#define MI_MEGA_PRIO_ROWS 1
+#endif
+#ifndef MI_MEGA_PRIO_LEVEL
+#define MI_MEGA_PRIO_LEVEL 1
+#endif
+#ifndef MI_MEGA_PRIO_C_SHIFT             /* phase C: a turn per 2^shift rows */
+#define MI_MEGA_PRIO_C_SHIFT 0
+#endif
 #ifndef MI_MEGA_PRIO_TURN_SHIFT
 #define MI_MEGA_PRIO_TURN_SHIFT 0
 #endif
@@ -431,13 +440,15 @@ template <class T, int N> MI_DEV void fresh(T (&x)[N]) {
 // both ready the hardware picks the OLDER one - the block that was dispatched first.  Measured (scripts/wf_skew.py): the
 // waves of blocks 0 .. n/2 - 1 end phase A 3.6 us before those of blocks n/2 .. n - 1, frame after frame (correlation
 // 0.91), then idle at the barrier while their SIMD runs the other wave alone - at half its issue rate.  The waves
-// therefore swap priority every row pair of phase A and every row of phase C: `turn` counts them, `younger` is the
-// block's half; whoever has the turn wins the ties.  46.9 -> 46.0 us per frame; the halves then end phase A 0.7 us apart
-// (3.8 before).  Also measured: slices of the CU's clock instead of turns (MI_MEGA_PRIO 3: 46.0 with 8192-cycle slices,
-// 46.4 with 2048, 47.8 with 32768), the younger block always first (MI_MEGA_PRIO 2: the asymmetry flips).
+// therefore swap priority every row of phases A, B and C: `turn` counts rows, `younger` is the block's half; whoever has
+// the turn wins the ties.  46.9 -> 44.8 us per frame (a turn per row PAIR of phase A: 46.0; none in phase C: + 1.1; two
+// turns per row - one for the demosaic, one for the rest - 46.9: worse than none); with a turn per pair the halves ended
+// phase A 0.7 us apart (3.8 before).  Also measured: slices of the CU's clock instead of turns (MI_MEGA_PRIO 3: 46.0 with
+// 8192-cycle slices, 46.4 with 2048, 47.8 with 32768), the younger block always first (MI_MEGA_PRIO 2: the asymmetry
+// flips), priority level 3 instead of 1 (the same), turns in phase D (nothing).
 MI_DEV void prio_turn(int turn, bool younger) {
 #if MI_MEGA_PRIO == 1
-  if ((((turn >> MI_MEGA_PRIO_TURN_SHIFT) & 1) != 0) == younger) asm volatile("s_setprio 1");
+  if ((((turn >> MI_MEGA_PRIO_TURN_SHIFT) & 1) != 0) == younger) asm volatile("s_setprio %0" :: "i"(MI_MEGA_PRIO_LEVEL));
   else asm volatile("s_setprio 0");
 #elif MI_MEGA_PRIO == 2              /* measurement: the younger block always wins */
   if (younger) asm volatile("s_setprio 3");
@@ -619,7 +630,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   static_for<0, ROWS / 2>([&](auto ibc) {
     constexpr int IB = decltype(ibc)::value, PH = IB % 3;
     const int r = r_begin + 2 * IB;
+#if !MI_MEGA_PRIO_ROWS
     prio_turn(IB, younger);
+#endif
     decode_row(raw[IB % 2][0], lut, lane, win[(2 * PH + 4) % 6]);
     decode_row(raw[IB % 2][1], lut, lane, win[(2 * PH + 5) % 6]);
     if constexpr (IB + 2 < ROWS / 2) {
@@ -638,9 +651,16 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       static_for<0, 2>([&](auto ic) {
         constexpr int I = decltype(ic)::value, RR = 2 * IB + I;
         const int row = r + I;
-        if constexpr (I == 1) prio_turn(IB, younger);
+#if MI_MEGA_PRIO_ROWS == 1           /* a turn per row instead of per row pair: 45.7 -> 44.9 us per frame */
+        prio_turn(RR, younger);
+#elif MI_MEGA_PRIO_ROWS == 2         /* two turns per row */
+        prio_turn(2 * RR, younger);
+#endif
         float v[24];
         accumulate_row<PR, PC, I, true>(w6, wq, v);
+#if MI_MEGA_PRIO_ROWS == 2
+        prio_turn(2 * RR + 1, younger);
+#endif
         if (MI_CENSUS(row < 2 || row >= p.H - 2, false)) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
         else if (MI_CENSUS(any_left || any_right, false)) border_fix_cols<PR, PC, I>(v, is_left, is_right, any_left, any_right);
         if (MI_CENSUS(p.has_ccm, false)) {            // bayer.py:152-153, sequential fp32 dot
@@ -737,6 +757,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     float sl0 = 0.f, sl1 = 0.f;
     static_for<0, ROWS>([&](auto rrc) {
       constexpr int RR = decltype(rrc)::value;
+      prio_turn(RR, younger);
       if (r_begin + RR < r_end) {
         uint32_t pk[12];
         resident_pk(rrc, pk);
@@ -812,7 +833,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
     if constexpr (RR >= NL) fresh(qr_[RR - NL]);
-    prio_turn(RR, younger);
+    prio_turn(RR >> MI_MEGA_PRIO_C_SHIFT, younger);
     if (r_begin + RR < r_end) {
       float t[24];
       resident(rrc, t);
