@@ -484,6 +484,11 @@ MI_DEV float pk_hi(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return
 #ifndef MI_MEGA_PREFETCH_AT_LATE
 #define MI_MEGA_PREFETCH_AT_LATE 8       /* LDS rows first: behind register row 8 */
 #endif
+// cache policy bits of the output stores: 2 = nt (streamed).  Measured per frame: 0 (none) 49.9, 1 (sc0) 51.4, 2 (nt) 44.9,
+// 3 (nt sc0) 44.8, 16 (sc1) 45.1, 17 (sc0 sc1) 45.1, 18 (nt sc1) 45.0, 19 (all) 45.0 us.
+#ifndef MI_MEGA_ST_AUX
+#define MI_MEGA_ST_AUX ST_STREAM
+#endif
 // LDS rows whose second Reinhard evaluation (it needs nothing from barrier 2) runs between a wave's post and its first
 // poll of that barrier, i.e. inside the wait for the slowest block
 #ifndef MI_MEGA_PRE2
@@ -915,7 +920,25 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
         for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[j]) : "v"(q[2 * j]), "v"(q[2 * j + 1]));
         uint4 mine[3];
         __builtin_memcpy(mine, pk, sizeof(mine));
-        wave_store_units<uint4, 3, ST_STREAM>(drsrc, row_base, lane_off, lane, stage, mine);   // streamed: nobody reads the output back
+        // Measurement variants (scripts/build_variant.sh; DESIGN.md 5.1d "what the stores cost"): 44.9 us per frame as shipped,
+        // 37.5 with MI_MEGA_TEST_NOSTORE, 39.4 with ..._STAGE_ONLY, 44.8 with ..._STORE_ONLY, 54.6 / 96.1 with ..._DIRECT=0 / 2.
+#if defined(MI_MEGA_TEST_DIRECT)       /* every lane stores its own 48 bytes: no LDS transpose, 16-byte pieces 48 apart */
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          buffer_store_unit<16, MI_MEGA_TEST_DIRECT>(drsrc, &mine[j], lane < active_lanes ? (uint32_t)lane * 48u + 16u * j : INVALID_OFF, row_base);
+#elif defined(MI_MEGA_TEST_STAGE_ONLY) /* the LDS transpose and the store instructions, but no byte reaches memory */
+        {
+          const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(io.dst, 0, p.H < 0 ? 16 : 0, 0x00020000);
+          wave_store_units<uint4, 3, ST_STREAM>(none, row_base, lane_off, lane, stage, mine);
+        }
+#elif defined(MI_MEGA_TEST_STORE_ONLY) /* the same bytes to the same places, not transposed (a scrambled image) */
+#pragma unroll
+        for (int j = 0; j < 3; ++j) buffer_store_unit<16, ST_STREAM>(drsrc, &mine[j], lane_off[j], row_base);
+#elif defined(MI_MEGA_TEST_NOSTORE)    /* the image is not stored */
+        asm volatile("" :: "v"(mine[0].x), "v"(mine[1].y), "v"(mine[2].z));
+#else
+        wave_store_units<uint4, 3, MI_MEGA_ST_AUX>(drsrc, row_base, lane_off, lane, stage, mine);   // streamed: nobody reads the output back
+#endif
         break;
       }
     }
