@@ -252,6 +252,21 @@ struct Stats2 {
     sgray += ga; sgray += gb;
     if constexpr (RGB) { s0 += a0; s0 += b0; s1 += a1; s1 += b1; s2 += a2; s2 += b2; }
   }
+  // a lane's row of eight pixels: one logarithm (of the product of the clamped gray values) instead of eight - add8_gray
+  template <bool RGB>
+  MI_DEV void add8(const float (&t)[24]) {
+    float c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const float ga = rgb_gray(t[3 * k], t[3 * k + 1], t[3 * k + 2]), gb = rgb_gray(t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+      gmin = __builtin_fminf(gmin, __builtin_fminf(ga, gb));          // v_min3_f32
+      gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(ga, gb));
+      c[k] = fmaxf(ga, 1e-4f); c[k + 1] = fmaxf(gb, 1e-4f);
+      sgray += ga; sgray += gb;
+      if constexpr (RGB) { s0 += t[3 * k]; s0 += t[3 * k + 3]; s1 += t[3 * k + 1]; s1 += t[3 * k + 4]; s2 += t[3 * k + 2]; s2 += t[3 * k + 5]; }
+    }
+    slog += hw_log2(((c[0] * c[1]) * (c[2] * c[3])) * ((c[4] * c[5]) * (c[6] * c[7])));
+  }
   // the same from two gray values (the whole-frame kernel takes them straight from the packed f16 pixels)
   // (min3 / max3 / max as asm: ga and gb come out of inline asm, and for values of unknown origin the compiler quiets
   // possible signalling NaNs with a v_max x, x before every min / max - 1.5 instructions per pixel for nothing)
@@ -264,6 +279,23 @@ struct Stats2 {
     slog += hw_log2(ca);
     slog += hw_log2(cb);
     sgray += ga; sgray += gb;
+  }
+  // The eight gray values of a lane's row at once.  sum(log2 g) = log2(prod g): one logarithm per row instead of eight
+  // (a transcendental issues at a fraction of the rate of a multiply).  The clamped values lie in [1e-4, ~1], so the
+  // product of eight stays above 1e-32 - a normal fp32 number; seven roundings of 2^-24 move log2 of the product by
+  // ~6e-7 absolute, the same order as the error of eight hardware logarithms (~1e-7 each, relative to values up to 13),
+  // and the scalars' contract is 1e-4.
+  MI_DEV void add8_gray(const float (&g)[8]) {
+    float c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      asm("v_min3_f32 %0, %0, %1, %2" : "+v"(gmin) : "v"(g[k]), "v"(g[k + 1]));
+      asm("v_max3_f32 %0, %0, %1, %2" : "+v"(gmax) : "v"(g[k]), "v"(g[k + 1]));
+      asm("v_max_f32 %0, 0x38d1b717, %1" : "=v"(c[k]) : "v"(g[k]));          // max(gray, 1e-4)
+      asm("v_max_f32 %0, 0x38d1b717, %1" : "=v"(c[k + 1]) : "v"(g[k + 1]));
+      sgray += g[k]; sgray += g[k + 1];
+    }
+    slog += hw_log2(((c[0] * c[1]) * (c[2] * c[3])) * ((c[4] * c[5]) * (c[6] * c[7])));
   }
   MI_DEV void finish() { gmin = fmaxf(gmin, 1e-4f); gmax = fmaxf(gmax, 1e-4f); }
 };
@@ -710,19 +742,16 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
       if constexpr (BOUNDS) {
         // statistics of tonemap.py:147-149 on the assumption lo = 0, hi = 1 (norm01 is then the identity)
         if (want_rgb) {
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) st.add2<true>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+          st.add8<true>(t);
         } else {
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) st.add2<false>(t[3 * k], t[3 * k + 1], t[3 * k + 2], t[3 * k + 3], t[3 * k + 4], t[3 * k + 5]);
+          st.add8<false>(t);
         }
       }
       if constexpr (EPI == S_STATS) {
         float n[24];
 #pragma unroll
         for (int j = 0; j < 24; ++j) n[j] = norm01(t[j], lo, inv);
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) st.add2<true>(n[3 * k], n[3 * k + 1], n[3 * k + 2], n[3 * k + 3], n[3 * k + 4], n[3 * k + 5]);
+        st.add8<true>(n);
       }
       if constexpr (EPI == S_RH_MINMAX || EPI == S_RH_STORE) {
         auto tone = [&](auto unit_c, auto ca0_c) {
