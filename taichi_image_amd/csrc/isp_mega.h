@@ -112,6 +112,15 @@ static_assert(MROW_BAR2 + 8 <= strm::PART_ROWS, "the whole-frame kernel's rows m
 static_assert(REC >= 48 && REC % 16 == 0, "three 16-byte chunks per record");
 constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
 
+// cache policy bits of the barrier's posts and polls.  16 = sc1.  Measured per frame (unit / non-unit): posts 17 (sc0 sc1)
+// 44.60 / 52.39 and 18 (nt sc1) 44.84 / 52.91, polls 17 44.58 / 52.27 and 18 45.57 / 54.33, both 17 44.61 / 52.26, both 19
+// 45.99 / 55.02, against 44.58 / 52.42 as shipped: nothing to gain.
+#ifndef MI_MEGA_POST_AUX
+#define MI_MEGA_POST_AUX 16
+#endif
+#ifndef MI_MEGA_POLL_AUX
+#define MI_MEGA_POLL_AUX 16
+#endif
 struct MArgs {
   SArgs s;                           // geometry and parameters shared by the frames of a launch (s.t.src / dst / fp / partials
                                      // and s.fp_w are per frame: FrameIO)
@@ -171,7 +180,7 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(area, 0, (int)((size_t)8 * stride * sizeof(float)), 0x00020000);
     const uint32_t off = lane < NCH ? (uint32_t)block * REC + 16u * lane : INVALID_OFF;
-    __builtin_amdgcn_raw_buffer_store_b128(mine, rs, off, 0, 16);      // aux 16 = sc1: write-through, visible to the other XCDs
+    __builtin_amdgcn_raw_buffer_store_b128(mine, rs, off, 0, MI_MEGA_POST_AUX);   // aux 16 = sc1: write-through, visible to the other XCDs
   }
 }
 
@@ -226,7 +235,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
     const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + 12u : INVALID_OFF;
     const bool idle = !(lane < 2 && watch >= 0);
-    auto ask = [&]() { return __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, 16); };
+    auto ask = [&]() { return __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, MI_MEGA_POLL_AUX); };
     auto nap = [&]() { for (unsigned z = 0; z <= m.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8); };
     auto there = [&](uint32_t q) { return __builtin_amdgcn_ballot_w64(!idle && q != tag) == 0; };
     uint32_t q0 = ask(); nap();
@@ -282,7 +291,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     // many records missing: the phase is still running elsewhere, poll rarely; few: the last arrivals, poll at once
     const unsigned naps = spins > 1 && __builtin_popcountll(missing) > 16 ? 4u * m.poll_sleep + 1u : m.poll_sleep;
     for (unsigned z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(8);
-    missing = round(std::integral_constant<int, 16>{});
+    missing = round(std::integral_constant<int, MI_MEGA_POLL_AUX>{});
   }
   if (stamps && lane == 0 && role == 0) stamps[0] = MI_STAMP_NOW();
   // The fold: fp32 (round 2 folded the sums in fp64 - 0.8 us of DPP trees per barrier with every wave of the chip
