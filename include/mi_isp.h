@@ -106,7 +106,10 @@ int mi_isp_transform(const void* src_dev, void* dst_dev, int Hs, int Ws, int dty
 /* ---- camera_isp.py: rolling metering + tonemap (stateful ISP semantics) ----------------- */
 /* metering_kernel + metering_images (camera_isp.py:142-175): stride-subsampled statistics of
  * n_images (H,W,3) images, blended into state9_dev (f32[9]) with weight alpha.
- * images_host: host array of n_images device pointers. */
+ * images_host: host array of n_images device pointers.
+ * One launch for up to 64 images (a grid barrier inside: at most one block per CU, so it needs no more of the chip than
+ * any kernel; a barrier that times out sets the workspace's fault word, mi_isp_workspace_check).  MI_ISP_METERING_LAUNCHES=4
+ * in the environment selects the four-launch path (bounds pass, finalize, statistics pass, finalize). */
 int mi_isp_metering(const void* const* images_host, int n_images, int H, int W, int stride,
                     int dtype, float* state9_dev, float alpha, void* ws_dev, void* stream);
 /* The two data passes of the same kernel, split so that a cross-GPU reduction can be

@@ -5,6 +5,8 @@
 #include "isp_math.h"
 
 #include <type_traits>
+#include <atomic>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -964,6 +966,233 @@ __global__ __launch_bounds__(EW_THREADS) void metering_kernel(const ew::PtrList 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The whole of update_metering (camera_isp.py:142-175) in ONE launch: bounds pass, blend of the bounds with the state,
+// statistics pass, update of the state.  The four launches it replaces (two data passes over a few MB and two
+// one-block finalize kernels, 4.5 - 7 us each) are all latency: 24 us per camera group.  At most one block per CU, all
+// resident, meeting at a grid barrier of the whole-frame kernel's kind (isp_mega.h): a block posts {values, tag} with one
+// 16-byte write-through store per record, every block polls all records (one per thread) until the tags are those of
+// this launch, and folds them in index order - every block derives the same bounds.  The tag is a quiet NaN with a
+// payload (no arithmetic of this library produces one, so nothing a workspace may hold from earlier kernels matches it),
+// handed out by the host, different for every launch and phase.  The second meeting point is one-sided: only block 0
+// waits, folds the sums in fp64 and updates the state with the libm-grade finalize of the multi-launch path.
+// A block that does not see its peers within `spin_limit` polls sets the workspace's fault word (mi_isp_workspace_check)
+// and goes on: no hang.
+// ---------------------------------------------------------------------------------------------
+constexpr int METER_MAX_BLOCKS = 256;
+constexpr int METER_THREADS = 1024;
+struct MeterFused {
+  ew::PtrList imgs;
+  int H, W, stride, bpi, n_images;
+  float* fp;                 // FrameParams of the workspace (FP_LO / FP_HI are left as the multi-launch path leaves them)
+  float* rec0;               // n_blocks records of 16 bytes: {min, max, -, tag}
+  float* rec1;               // n_blocks records of 48 bytes: {gmin, gmax, slog2, tag} {sgray, s0, s1, tag} {s2, -, -, tag}
+  float* state9;
+  float alpha, n_px;
+  uint32_t tag;              // phase 0; phase 1 = tag + 1
+  unsigned spin_limit;
+  unsigned* fault;
+};
+
+template <class T>
+__global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const MeterFused a) {
+#pragma clang fp contract(fast)
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[METER_THREADS / 64][8];
+  __shared__ float sh_b[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // grid = (blocks per image, images): the pointer list is indexed by blockIdx.y itself (a computed index sends the whole
+  // argument struct through scratch)
+  const int n_blocks = a.bpi * a.n_images, part = blockIdx.x, block = blockIdx.y * a.bpi + part;
+  const T* img = static_cast<const T*>(a.imgs.p[blockIdx.y]);
+  const int hs = (a.H + a.stride - 1) / a.stride, ws = (a.W + a.stride - 1) / a.stride;
+  const int n = hs * ws;
+  auto pixel = [&](int i, float (&x)[3]) {
+    const int sr = i / ws, sc = i - sr * ws;
+    const T* p = img + ((size_t)(sr * a.stride) * a.W + (size_t)sc * a.stride) * 3;
+    x[0] = (float)p[0]; x[1] = (float)p[1]; x[2] = (float)p[2];
+  };
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(a.rec0, 0, n_blocks * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(a.rec1, 0, n_blocks * 48, 0x00020000);
+
+#ifdef MI_METER_STAMPS
+  unsigned long long* stamps_ = reinterpret_cast<unsigned long long*>(a.rec1 + 3 * 1024 * 4) + (size_t)block * 8;
+#define MI_METER_STAMP(i) do { if (threadIdx.x == 0) stamps_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MI_METER_STAMP(i) do { } while (0)
+#endif
+  MI_METER_STAMP(0);
+  // ---- pass 1: bounds of the samples (camera_isp.py:152-153) ----
+  float vmin = __builtin_inff(), vmax = -__builtin_inff();
+  // (the gather is bound by latency: four independent samples in flight per thread)
+  const int step = a.bpi * METER_THREADS;
+  for (int i0 = part * METER_THREADS + threadIdx.x; i0 < n; i0 += 4 * step) {
+    float x[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pixel(i0 + u * step < n ? i0 + u * step : i0, x[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                        // (a repeated sample changes neither bound)
+      vmin = fminf(vmin, fminf(x[u][0], fminf(x[u][1], x[u][2])));
+      vmax = fmaxf(vmax, fmaxf(x[u][0], fmaxf(x[u][1], x[u][2])));
+    }
+  }
+  vmin = wave_min(vmin); vmax = wave_max(vmax);
+  if (lane == 0) { red[wave][0] = vmin; red[wave][1] = vmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float lo = red[0][0], hi = red[0][1];
+    for (int w = 1; w < METER_THREADS / 64; ++w) { lo = fminf(lo, red[w][0]); hi = fmaxf(hi, red[w][1]); }
+    const u4 mine = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi), 0u, a.tag};
+    __builtin_amdgcn_raw_buffer_store_b128(mine, r0, (uint32_t)block * 16u, 0, 16);     // sc1: write-through
+  }
+  MI_METER_STAMP(1);
+  // ---- every block: all records of pass 1 (wave 0 polls, four records per lane; the other waves wait at the barrier) ----
+  if (wave == 0) {
+    uint32_t rx[4] = {0u, 0u, 0u, 0u}, ry[4] = {0u, 0u, 0u, 0u};   // (copied out where they are loaded: hipcc 7.2 read .x for .y
+    bool have[4];                                                  // of a vector carried round the loop)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) have[j] = j * 64 + lane >= n_blocks;
+    unsigned spins = 0;
+    for (;;) {
+      u4 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        t[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, have[j] ? 0xFFFFFFFFu : (uint32_t)(j * 64 + lane) * 16u, 0, 16);
+      bool all = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!have[j] && t[j].w == a.tag) { rx[j] = t[j].x; ry[j] = t[j].y; have[j] = true; }
+        all = all && have[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+      if (++spins > a.spin_limit) {
+        if (lane == 0) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j * 64 + lane < n_blocks && have[j]) {
+        lo = fminf(lo, __builtin_bit_cast(float, rx[j])); hi = fmaxf(hi, __builtin_bit_cast(float, ry[j]));
+      }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if (lane == 0) {
+      // camera_isp.py:156-157: b = lerp(alpha, new, prev) = new + alpha * (prev - new)  (ew::FIN_ISP_BOUNDS)
+      sh_b[0] = lo + a.alpha * (a.state9[0] - lo);
+      sh_b[1] = hi + a.alpha * (a.state9[1] - hi);
+      if (block == 0) { a.fp[FP_LO] = sh_b[0]; a.fp[FP_HI] = sh_b[1]; }
+    }
+  }
+  __syncthreads();
+  MI_METER_STAMP(2);
+  // ---- pass 2: statistics of the samples normalised by the blended bounds (camera_isp.py:117-128) ----
+  const float bmin = sh_b[0], dinv = 1.0f / (sh_b[1] - sh_b[0] + 1e-6f);   // camera_isp.py:119
+  StatsAcc st; st.init();
+  for (int i0 = part * METER_THREADS + threadIdx.x; i0 < n; i0 += 4 * step) {
+    float x[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pixel(i0 + u * step < n ? i0 + u * step : i0, x[u]);
+    // (all four samples loaded before the first is consumed: left alone, the compiler sinks each load into its condition
+    // and the thread waits for four round trips in a row - pass 2 then took 10 - 17 us against 4 - 6 of pass 1)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(x[u][0]), "+v"(x[u][1]), "+v"(x[u][2]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * step < n) st.add((x[u][0] - bmin) * dinv, (x[u][1] - bmin) * dinv, (x[u][2] - bmin) * dinv);
+  }
+  MI_METER_STAMP(6);
+  {
+    const float v7[7] = {wave_min(st.gmin), wave_max(st.gmax), wave_sum(st.slog), wave_sum(st.sgray), wave_sum(st.s0),
+                         wave_sum(st.s1), wave_sum(st.s2)};
+    __syncthreads();
+    MI_METER_STAMP(7);
+    if (lane == 0)
+      for (int k = 0; k < 7; ++k) red[wave][k] = v7[k];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      float t[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        float r = red[0][k];
+#pragma unroll
+        for (int w = 1; w < METER_THREADS / 64; ++w) r = k == 0 ? fminf(r, red[w][k]) : (k == 1 ? fmaxf(r, red[w][k]) : r + red[w][k]);
+        t[k] = r;
+      }
+      // chunk c of the block's record.  Selected, not indexed: a local array indexed by the thread id is "promoted" to LDS
+      // slots addressed by the flat thread id, for which the kernel reads the block size from the dispatch packet - in
+      // host memory, 13 - 27 us away (measured: the whole kernel took 34 us, 20 of them here).
+      const int c = threadIdx.x;
+      const float m0 = c == 0 ? t[0] : (c == 1 ? t[3] : t[6]);
+      const float m1 = c == 0 ? t[1] : (c == 1 ? t[4] : 0.f);
+      const float m2 = c == 0 ? t[2] : (c == 1 ? t[5] : 0.f);
+      const u4 mine = {__builtin_bit_cast(uint32_t, m0), __builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m2), a.tag + 1u};
+      __builtin_amdgcn_raw_buffer_store_b128(mine, r1, (uint32_t)block * 48u + 16u * c, 0, 16);
+    }
+  }
+  MI_METER_STAMP(3);
+  if (block != 0) return;
+  // ---- block 0, wave 0: all records of pass 2 (four per lane), sums in fp64, the state (ew::FIN_ISP_STATS) ----
+  if (wave != 0) return;
+  {
+    uint32_t w7[4][7];
+    bool have[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      have[j] = j * 64 + lane >= n_blocks;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) w7[j][k] = 0u;
+    }
+    unsigned spins = 0;
+    for (;;) {
+      bool all = true;
+      u4 t0[4], t1[4], t2[4];                              // all twelve loads of a round in flight together
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t off = have[j] ? 0xFFFFFFFFu : (uint32_t)(j * 64 + lane) * 48u;
+        t0[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0, 16);
+        t1[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, off + (have[j] ? 0u : 16u), 0, 16);
+        t2[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, off + (have[j] ? 0u : 32u), 0, 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!have[j] && t0[j].w == a.tag + 1u && t1[j].w == a.tag + 1u && t2[j].w == a.tag + 1u) {
+          w7[j][0] = t0[j].x; w7[j][1] = t0[j].y; w7[j][2] = t0[j].z; w7[j][3] = t1[j].x; w7[j][4] = t1[j].y; w7[j][5] = t1[j].z;
+          w7[j][6] = t2[j].x;
+          have[j] = true;
+        }
+        all = all && have[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+      if (++spins > a.spin_limit) {
+        if (lane == 0) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    float gmin = __builtin_inff(), gmax = -__builtin_inff();
+    double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)                          // records in index order within the lane, lanes by the DPP tree: fixed
+      if (j * 64 + lane < n_blocks && have[j]) {
+        gmin = fminf(gmin, __builtin_bit_cast(float, w7[j][0])); gmax = fmaxf(gmax, __builtin_bit_cast(float, w7[j][1]));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sum[k] += (double)__builtin_bit_cast(float, w7[j][2 + k]);
+      }
+    MI_METER_STAMP(4);
+    gmin = wave_min(gmin); gmax = wave_max(gmax);
+    double tot[7];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) tot[2 + k] = wave_sum(sum[k]);
+    if (lane == 0) {
+      tot[0] = gmin; tot[1] = gmax;
+      ew::FinArgs fa = {};
+      fa.fp = a.fp; fa.state9 = a.state9; fa.bounds_in = sh_b; fa.n_px = a.n_px; fa.alpha = a.alpha;
+      ew::finalize_scalars(ew::FIN_ISP_STATS, fa, tot);
+    }
+    MI_METER_STAMP(5);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // finalize: one block folds the per-block partials (sums in fp64) and thread 0 derives the
 // scalars of the next pass with the accurate libm-grade functions.
 // ---------------------------------------------------------------------------------------------
@@ -1493,6 +1722,44 @@ extern "C" int mi_isp_metering_combine_sums(const float* gathered, int n_ranks, 
   return 0;
 }
 
+// One launch (metering_fused_kernel) when the group's blocks fit one per CU; MI_ISP_METERING_LAUNCHES=4 in the environment
+// forces the four-launch path (measurement, and the reference the fused path is tested against).
+static std::atomic<uint32_t> g_meter_launches{0};
+static int metering_fused(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
+                          float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done) {
+  *done = false;
+  const char* env = getenv("MI_ISP_METERING_LAUNCHES");       // (read per call: a test switches it)
+  if ((env && atoi(env) == 4) || n_images > 64 || n_images > METER_MAX_BLOCKS) return 0;
+  int dev = 0, n_cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 0;
+  const int max_blocks = n_cus < METER_MAX_BLOCKS ? n_cus : METER_MAX_BLOCKS;
+  if (n_images > max_blocks || cap < 4 * METER_MAX_BLOCKS) return 0;
+  const int hs = (H + stride - 1) / stride, wss = (W + stride - 1) / stride;
+  int bpi = (hs * wss + METER_THREADS * 2 - 1) / (METER_THREADS * 2);
+  if (bpi > max_blocks / n_images) bpi = max_blocks / n_images;
+  if (bpi < 1) bpi = 1;
+  MeterFused a = {};
+  for (int i = 0; i < 64; ++i) a.imgs.p[i] = i < n_images ? images[i] : nullptr;
+  a.H = H; a.W = W; a.stride = stride; a.bpi = bpi; a.n_images = n_images;
+  a.fp = fp; a.rec0 = partials; a.rec1 = partials + cap;       // partial rows 0 and 1..3 (cap >= 1024 floats each)
+  a.state9 = state9; a.alpha = alpha; a.n_px = (float)((int64_t)n_images * hs * wss);
+  // a quiet NaN with a payload, two per launch (0x7FC00001 ...): see the kernel's head
+  const uint32_t k = g_meter_launches.fetch_add(1, std::memory_order_relaxed);
+  a.tag = 0x7FC00001u + 2u * (k % 0x1FFFFFu);
+  a.spin_limit = 2000000u;                                     // ~1 s of polling
+  a.fault = reinterpret_cast<unsigned*>(fp) + 62;              // FP_ERROR (isp_mega.h): what mi_isp_workspace_check reads
+  const int rc = dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((metering_fused_kernel<T>), dim3(bpi, n_images), dim3(METER_THREADS), 0, s, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+  });
+  if (rc) return rc;
+  *done = true;
+  return 0;
+}
+
 extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype,
                                float* state9, float alpha, void* ws, void* stream) {
   if (int rc = metering_check(images, n_images, H, W, stride, dtype, ws)) return rc;
@@ -1501,6 +1768,11 @@ extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, i
   float* fp = static_cast<float*>(ws);
   float* partials = fp + FP_COUNT;
   const int cap = mi_partial_cap(H, W);
+  {
+    bool done = false;
+    if (int rc = metering_fused(images, n_images, H, W, stride, dtype, state9, alpha, fp, partials, cap, s, &done)) return rc;
+    if (done) return 0;
+  }
   int nb = 0;
   if (int rc = metering_pass(0, images, n_images, H, W, stride, dtype, nullptr, partials, cap, &nb, s)) return rc;
   FinArgs fa = {};

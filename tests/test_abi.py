@@ -183,3 +183,7 @@ def test_no_kernel_of_the_library_touches_scratch():
     assert any("frame_kernel" in k for k in res) and any("rgb_pass_kernel" in k for k in res)
     bad = {k: v for k, v in res.items() if v["scratch"] or v["vgpr_spills"]}
     assert not bad, bad
+    # ... and none reads its dispatch packet (host memory): the one-launch metering kernel did, for a local array indexed by
+    # the thread id that the compiler moved to LDS slots addressed by the flat thread id - 20 of its 34 us
+    reads = [k for k, v in res.items() if v["dispatch_ptr"]]
+    assert not reads, reads

@@ -707,6 +707,34 @@ def test_isp_sharded_metering_path_equals_fused(ti, rng, dev):
             assert_close(y.cpu().numpy(), x.cpu().numpy(), f"u8 output, call {step}")
 
 
+@pytest.mark.parametrize("shape,n", [((96, 160), 3), ((8, 16), 1), ((200, 520), 6), ((768, 1024), 6)])
+def test_isp_metering_in_one_launch_equals_four_launches(ti, rng, dev, shape, n, monkeypatch):
+    """update_metering as ONE kernel with a grid barrier inside (mi_isp_metering's default) against the four launches it
+    replaces (MI_ISP_METERING_LAUNCHES=4: bounds pass, finalize, statistics pass, finalize) and against the oracle: the
+    rolling state over three calls, and the u8 outputs that follow from it."""
+    H, W = shape
+    frames = [torch.from_numpy(natural_packed12(rng, H, W)).to(dev) for _ in range(n)]
+    a = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+    b = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+    for step in range(3):
+        monkeypatch.delenv("MI_ISP_METERING_LAUNCHES", raising=False)
+        fa = [a.load_packed12(f) for f in frames]
+        oa = a.tonemap_reinhard(fa, gamma=0.6)
+        torch.cuda.synchronize()
+        monkeypatch.setenv("MI_ISP_METERING_LAUNCHES", "4")
+        fb = [b.load_packed12(f) for f in frames]
+        ob = b.tonemap_reinhard(fb, gamma=0.6)
+        torch.cuda.synchronize()
+        assert_close(a.metrics.cpu().numpy(), b.metrics.cpu().numpy(), f"metering state, call {step}", rel=1e-5)
+        for x, y in zip(oa, ob):
+            assert_close(x.cpu().numpy(), y.cpu().numpy(), f"u8 output, call {step}")
+    monkeypatch.delenv("MI_ISP_METERING_LAUNCHES", raising=False)
+    from taichi_image_amd import _native
+    ws = _native.workspace(H, W, dev)
+    off = int(_native.lib().mi_isp_workspace_error_offset(H, W))
+    assert int(ws[off:off + 4].view(torch.int32).item()) == 0, "the metering kernel's grid barrier timed out"
+
+
 @pytest.mark.parametrize("cam", ["Camera16", "Camera32"])
 def test_isp_tonemap_reinhard_yuv420_fused(ti, rng, dev, cam):
     """The fused second pass + YUV 4:2:0 conversion equals converting the u8 outputs of tonemap_reinhard, bit
