@@ -235,6 +235,9 @@ MI_DEV void wave_store_row_t(__amdgpu_buffer_rsrc_t rsrc, uint32_t row_base, con
 // clamp max(gray, 1e-4) (monotone) is applied once to the reduced values; the channel sums are only accumulated when
 // something consumes them (RGB: color_adapt != 0 - otherwise mean3 == gray_mean, tonemap.py:119).
 // ---------------------------------------------------------------------------------------------
+#ifndef MI_STREAM_PRIO
+#define MI_STREAM_PRIO 1
+#endif
 #pragma clang fp contract(fast)
 struct Stats2 {
   float gmin, gmax, slog, sgray, s0, s1, s2;
@@ -655,6 +658,7 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
   const bool any_left = __builtin_amdgcn_ballot_w64(is_left) != 0, any_right = __builtin_amdgcn_ballot_w64(is_right) != 0;
 
+  const bool younger = blockIdx.x * 2 >= gridDim.x;   // (with all blocks resident: the second block of its CU)
   // ---- one row pair: rotation PH of the ring (PH = pair index % 3) ----
   auto body = [&](auto ph_c, int i) {
     constexpr int PH = decltype(ph_c)::value;
@@ -672,6 +676,15 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
     static_for<0, 2>([&](auto ic) {
       constexpr int I = decltype(ic)::value;
       const int row = r + I;
+#if MI_STREAM_PRIO
+      // issue-priority turns between the two waves of a SIMD (isp_mega.h, prio_turn): the second half of the grid holds
+      // priority in the odd rows, the first half in the even ones.  Only the load kernel: measured per 4K frame, S_STORE
+      // 22.3 -> 21.4 us; the passes of the multi-pass chain, two kernels at a time on two streams, got slower with it
+      // (66.6 -> 67.8 us per frame) - "second half of the grid" says nothing about who shares a SIMD there.
+      if constexpr (EPI == S_STORE) {
+        if (younger == (I == 1)) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");
+      }
+#endif
       float v[24];
       accumulate_row<PR, PC, I, EXACT>(w6, wq, v);
 #ifndef MI_STREAM_ANALYZE   /* reading aid: the hot path alone (scratch compile only) */
@@ -809,6 +822,9 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
     body(std::integral_constant<int, 2>{}, i + 2);
     MI_SSTAMP(5 + (i < 9 ? i : 9));
   }
+#if MI_STREAM_PRIO
+  if constexpr (EPI == S_STORE) asm volatile("s_setprio 0");
+#endif
   MI_SSTAMP(15);
 
   // ---- reductions: one partial per block ----

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
     }
   };
 
+  const bool younger = blockIdx.x * 2 >= gridDim.x;
   auto body = [&](auto ph_c, int i) {
     constexpr int PH = decltype(ph_c)::value;
     const int r = r_begin + 2 * i;
@@ -284,6 +285,9 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
       constexpr int I = decltype(ic)::value;
       const int row = r + I;
       if (row > r_last) return;
+#if MI_STREAM_PRIO
+      if (younger == (I == 1)) asm volatile("s_setprio 1"); else asm volatile("s_setprio 0");   // (strm::stream_kernel)
+#endif
       float v[24];
       accumulate_row<PR, PC, I, true>(w6, wq, v);
       if (row < 2 || row >= p.H - 2) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
@@ -329,6 +333,9 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
     body(std::integral_constant<int, 1>{}, i + 1);
     body(std::integral_constant<int, 2>{}, i + 2);
   }
+#if MI_STREAM_PRIO
+  asm volatile("s_setprio 0");
+#endif
   MI_SSTAMP(5);
 }
 
