@@ -7,7 +7,7 @@ acc = collections.defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"]
     short = ("P1 rgb_pass<5>" if "Li5EEE" in name else "P2 rgb_pass<6>" if "Li6EEE" in name else "metering<0>" if "metering_kernel" in name and "Li0EE" in name
-             else "metering<1>" if "metering_kernel" in name else "load stream_kernel<S_STORE>" if "stream_kernel" in name else
+             else "metering<1>" if "metering_kernel" in name else "metering (one launch)" if "metering_fused" in name else "load stream_kernel<S_STORE>" if "stream_kernel" in name else
              "load resize_kernel" if "resize_kernel" in name else "finalize" if "finalize_kernel" in name else None)
     if short is None: continue
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
