@@ -6,6 +6,7 @@
 
 #include <type_traits>
 #include <atomic>
+#include <mutex>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -1725,6 +1726,10 @@ extern "C" int mi_isp_metering_combine_sums(const float* gathered, int n_ranks, 
 // One launch (metering_fused_kernel) when the group's blocks fit one per CU; MI_ISP_METERING_LAUNCHES=4 in the environment
 // forces the four-launch path (measurement, and the reference the fused path is tested against).
 static std::atomic<uint32_t> g_meter_launches{0};
+// Two of these kernels from two streams fit the chip side by side, three may each get a part of it and wait for the rest
+// forever (until the poll budget: fault word, no hang).  So the launches of a process are put in order per device: a launch
+// on another stream than the previous one waits for the event recorded behind that one.
+static struct { std::mutex mu; hipEvent_t done[16] = {}; hipStream_t last[16] = {}; } g_meter_order;
 static int metering_fused(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
                           float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done) {
   *done = false;
@@ -1733,6 +1738,10 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
   int dev = 0, n_cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 0;
+  if (dev < 0 || dev >= 16) return 0;
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap_status);
+  if (cap_status != hipStreamCaptureStatusNone) return 0;     // (a capture cannot be put in order: the four launches)
   const int max_blocks = n_cus < METER_MAX_BLOCKS ? n_cus : METER_MAX_BLOCKS;
   if (n_images > max_blocks || cap < 4 * METER_MAX_BLOCKS) return 0;
   const int hs = (H + stride - 1) / stride, wss = (W + stride - 1) / stride;
@@ -1749,6 +1758,9 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
   a.tag = 0x7FC00001u + 2u * (k % 0x1FFFFFu);
   a.spin_limit = 2000000u;                                     // ~1 s of polling
   a.fault = reinterpret_cast<unsigned*>(fp) + 62;              // FP_ERROR (isp_mega.h): what mi_isp_workspace_check reads
+  std::lock_guard<std::mutex> lock(g_meter_order.mu);
+  if (!g_meter_order.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_meter_order.done[dev], hipEventDisableTiming));
+  else if (g_meter_order.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, g_meter_order.done[dev], 0));
   const int rc = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((metering_fused_kernel<T>), dim3(bpi, n_images), dim3(METER_THREADS), 0, s, a);
@@ -1756,6 +1768,8 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
     return 0;
   });
   if (rc) return rc;
+  MI_HIP(hipEventRecord(g_meter_order.done[dev], s));
+  g_meter_order.last[dev] = s;
   *done = true;
   return 0;
 }

@@ -735,6 +735,40 @@ def test_isp_metering_in_one_launch_equals_four_launches(ti, rng, dev, shape, n,
     assert int(ws[off:off + 4].view(torch.int32).item()) == 0, "the metering kernel's grid barrier timed out"
 
 
+def test_isp_metering_kernels_of_several_streams_are_put_in_order(ti, rng, dev):
+    """Four camera groups on four streams at once: the one-launch metering kernels (a grid barrier inside each) are
+    serialised by the library, so every group's state and outputs equal those of the same group run alone."""
+    from taichi_image_amd import _native
+    H, W = 768, 1024
+    groups = [[torch.from_numpy(natural_packed12(rng, H, W, dark=0.03 * g)).to(dev) for _ in range(6)] for g in range(4)]
+    alone = []
+    for frames in groups:
+        cam = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+        for _ in range(2):
+            outs = cam.tonemap_reinhard([cam.load_packed12(f) for f in frames], gamma=0.6)
+        torch.cuda.synchronize()
+        alone.append((cam.metrics.clone(), [o.clone() for o in outs]))
+    streams = [torch.cuda.Stream(device=dev) for _ in groups]
+    cams = [ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev) for _ in groups]
+    torch.cuda.synchronize()
+    res = [None] * len(groups)
+    for _ in range(2):
+        for g, (frames, st_) in enumerate(zip(groups, streams)):
+            with torch.cuda.stream(st_):
+                res[g] = cams[g].tonemap_reinhard([cams[g].load_packed12(f) for f in frames], gamma=0.6)
+    torch.cuda.synchronize()
+    for g in range(len(groups)):
+        assert torch.equal(cams[g].metrics, alone[g][0]), f"group {g}: metering state"
+        for x, y in zip(res[g], alone[g][1]):
+            assert torch.equal(x, y), f"group {g}: u8 output"
+        ws = None
+    for st_ in streams:
+        with torch.cuda.stream(st_):
+            ws = _native.workspace(H, W, dev)
+            off = int(_native.lib().mi_isp_workspace_error_offset(H, W))
+            assert int(ws[off:off + 4].view(torch.int32).item()) == 0, "a metering kernel's grid barrier timed out"
+
+
 @pytest.mark.parametrize("cam", ["Camera16", "Camera32"])
 def test_isp_tonemap_reinhard_yuv420_fused(ti, rng, dev, cam):
     """The fused second pass + YUV 4:2:0 conversion equals converting the u8 outputs of tonemap_reinhard, bit
