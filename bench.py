@@ -279,11 +279,35 @@ def spawn_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
+    # rank 0's line is read by a thread; the ranks are watched: when one ends badly (no such GPU, a failed build ...) the
+    # others - which would wait in the rendezvous or in a barrier for minutes - are ended too (these exact processes)
+    import threading
+    import time
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            failed = abs(bad[0])
+            sys.stderr.write(f"bench.py: a rank ended with code {bad[0]}; ending the other ranks\n")
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out)
+    reader.join(timeout=5)
+    sys.stdout.write("".join(o for o in out if o))
     sys.stdout.flush()
-    return max((abs(rc) for rc in rcs), default=0)
+    return failed or max((abs(rc) for rc in rcs), default=0)
 
 
 def main():
