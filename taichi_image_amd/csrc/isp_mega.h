@@ -498,6 +498,12 @@ MI_DEV float pk_hi(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return
 #ifndef MI_MEGA_ST_AUX
 #define MI_MEGA_ST_AUX ST_STREAM
 #endif
+#ifndef MI_MEGA_D_STAGGER
+#define MI_MEGA_D_STAGGER 0
+#endif
+#ifndef MI_MEGA_PRIO_A_BIAS
+#define MI_MEGA_PRIO_A_BIAS 0
+#endif
 #ifndef MI_MEGA_PRIO_RESET_C
 #define MI_MEGA_PRIO_RESET_C 0
 #endif
@@ -600,9 +606,17 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   __syncthreads();                                    // table, tickets, flags, `arrived`: the kernel's only workgroup barrier
   constexpr bool want_rgb = RGB;                        // the host picks the kernel by p.ca != 0
 
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // the thread's id, re-derived (lane from the exec mask, volatile: not hoisted) - so that not even threadIdx.x occupies
+  // a register around the loop
+  auto thread_id = [&]() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return wave_s * 64 + l;
+  };
   for (int f = 0; f < mb.n_frames; ++f) {
-  int tid_ = threadIdx.x, bid_ = blockIdx.x;
-  asm volatile("" : "+v"(tid_), "+s"(bid_));
+  int tid_ = thread_id(), bid_ = blockIdx.x;
+  asm volatile("" : "+s"(bid_));
   const Geo G = geo(tid_, bid_);
   const int lane = G.lane, wave = G.wave, g = G.g, bx = G.bx, r_begin = G.r_begin, r_end = G.r_end, active_lanes = G.active_lanes;
   const bool younger = bid_ >= (a.n_blocks >> 1);       // the second of the two blocks of its CU (dispatch order)
@@ -672,7 +686,8 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
         constexpr int I = decltype(ic)::value, RR = 2 * IB + I;
         const int row = r + I;
 #if MI_MEGA_PRIO_ROWS == 1           /* a turn per row instead of per row pair: 45.7 -> 44.9 us per frame */
-        prio_turn(RR, younger);
+        if constexpr (RR < MI_MEGA_PRIO_A_BIAS) prio_turn(0, younger);   // (the older block's waves catch up first)
+        else prio_turn(RR, younger);
 #elif MI_MEGA_PRIO_ROWS == 2         /* two turns per row */
         prio_turn(2 * RR, younger);
 #endif
@@ -812,9 +827,16 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   MI_MSTAMP(4);
   ReinhardK rk;
   const bool ca0 = MI_CENSUS(p.ca == 0.f, true);        // runtime on purpose: see the note on register allocation at the kernel's head
-  rk.la = vgpr(p.la); rk.ca = vgpr(p.ca);
+  rk.la = vgpr(p.la);
   rk.map_key = vgpr(sh_fp[FP_MAPKEY]); rk.ei = vgpr(sh_fp[FP_EI]);
-  rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
+  rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]);
+  if constexpr (RGB) {
+    rk.ca = vgpr(p.ca); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
+  } else {
+    // this kernel is only launched with color_adapt == 0 (mean3 is then the same for the three channels, tonemap.py:119):
+    // the operands of the other arm - never executed here - share registers instead of taking three more
+    rk.ca = rk.la; rk.mean3[1] = rk.mean3[0]; rk.mean3[2] = rk.mean3[0];
+  }
 
   // Reinhard of one resident row (tonemap.py:120-131): q[24].  UNIT: bounds exactly (0, 1), the normalisation is the
   // identity; CA0: color_adapt == 0, one pow per pixel.  The variant is chosen ONCE per phase, outside the row loops: the
@@ -931,6 +953,17 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   MI_MSTAMP(7);
   const float lo2 = vgpr(sh_fp[FP_LO2]), inv2 = vgpr(sh_fp[FP_INV2]);
   const float out_scale = vgpr(p.out_scale);
+#if MI_MEGA_D_STAGGER > 0
+  // Measurement: the older block's waves let the younger one's store first (phase D is bound by the chip's write rate:
+  // whoever stores first is done first and goes on to the next frame's phase A - arithmetic - while the other half's rows
+  // drain; MI_MEGA_PRIO_A_BIAS then gives the late half the priority in the first rows of phase A).  Per frame, naps of
+  // 1024 cycles / biased rows: 2 / 0 44.79, 2 / 6 45.21, 4 / 0 44.66, 4 / 6 44.89, 6 / 0 44.55, 6 / 6 44.43, 10 / 6 45.05,
+  // 10 / 12 44.72, 14 / 8 45.99 us against 44.4 without: a wave alone on its SIMD does not make up for the wait.
+  if (!younger) {
+#pragma unroll 1
+    for (int z = 0; z < MI_MEGA_D_STAGGER; ++z) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
 
   // ================================ phase D: final map (tonemap.py:154) ================================
   uint32_t lane_off[6];
@@ -988,7 +1021,8 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   // the start of the phase -, then Reinhard again for the other LDS rows (their mapped values had no room to stay) while
   // those stores drain.  Order 0 (round 2): LDS rows first, the burst of the register rows' stores at the end.
   constexpr bool REGS_FIRST = MI_MEGA_D_ORDER == 1 && PRE2 >= 1;   // (row 0's slot, the register rows' staging, must be free)
-  auto lds_rows = [&]() {
+  auto lds_rows = [&](auto regs_first_c) {
+    constexpr bool REGS_FIRST = decltype(regs_first_c)::value;
     dispatch([&](auto unit_c, auto ca0_c) {
       static_for<PRE2, NL>([&](auto rrc) {
         constexpr int RR = decltype(rrc)::value;
@@ -1008,7 +1042,8 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       });
     });
   };
-  auto reg_rows = [&]() {
+  auto reg_rows = [&](auto regs_first_c) {
+    constexpr bool REGS_FIRST = decltype(regs_first_c)::value;
     static_for<NL, ROWS>([&](auto rrc) {
       constexpr int RR = decltype(rrc)::value;
       if (r_begin + RR < r_end) {
@@ -1027,12 +1062,14 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     constexpr int RR = decltype(rrc)::value;
     if (r_begin + RR < r_end) finish_row(rrc, qpre[RR]);
   });
+  // (Measured and taken out: the two blocks of a CU taking phase D in opposite orders - the younger one's waves storing
+  // their register rows at once, the older one's mapping their LDS rows first: both orders in one body cost 54 - 73 spills.)
   if constexpr (REGS_FIRST) {
-    reg_rows();
-    lds_rows();
+    reg_rows(std::true_type{});
+    lds_rows(std::true_type{});
   } else {
-    lds_rows();
-    reg_rows();
+    lds_rows(std::false_type{});
+    reg_rows(std::false_type{});
   }
 
   MI_MSTAMP(8);
