@@ -145,6 +145,46 @@ struct MBatch {
   FrameIO io[MAX_BATCH];
 };
 
+// Wave reductions for the posts and folds - the code every wave of the chip waits for.  The same DPP tree as
+// isp_common.h's wave_min / wave_max / wave_sum (same order, same bits), but ONE instruction per step (v_min_f32_dpp ...)
+// instead of four: written in C, every step became v_max x, x (the compiler quiets possible signalling NaNs around
+// fminf / fmaxf of values it cannot trace) + v_mov_dpp + v_max + v_min.  The s_nop 1 in front of each step is the DPP
+// hazard (two wait states after the VALU write of the source), which nobody inserts inside inline assembly.
+#define MI_DPP_STEP(OP, CTRL) "s_nop 1\n\t" OP " %0, %0, %0 " CTRL "\n\t"
+#define MI_DPP_TREE(OP)                                                                       \
+  MI_DPP_STEP(OP, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")                           \
+  MI_DPP_STEP(OP, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")                           \
+  MI_DPP_STEP(OP, "row_half_mirror row_mask:0xf bank_mask:0xf")                               \
+  MI_DPP_STEP(OP, "row_mirror row_mask:0xf bank_mask:0xf")                                    \
+  MI_DPP_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                  \
+  MI_DPP_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+MI_DEV float wmin(float v) {
+  asm volatile(MI_DPP_TREE("v_min_f32_dpp") : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+MI_DEV float wmax(float v) {
+  asm volatile(MI_DPP_TREE("v_max_f32_dpp") : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+MI_DEV float wsum(float v) {
+  asm volatile(MI_DPP_TREE("v_add_f32_dpp") : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef MI_DPP_TREE
+#undef MI_DPP_STEP
+
+#ifndef MI_MEGA_ASM_REDUCE
+#define MI_MEGA_ASM_REDUCE 1
+#endif
+#if MI_MEGA_ASM_REDUCE
+#define MI_WMIN wmin
+#define MI_WMAX wmax
+#define MI_WSUM wsum
+#else
+#define MI_WMIN wave_min
+#define MI_WMAX wave_max
+#define MI_WSUM wave_sum
+#endif
 // The block's contribution to a grid-wide reduction = its arrival at the barrier: every wave reduces in registers and
 // leaves its row in LDS; the wave that arrives last combines the rows in wave order and stores the block's chunks
 // {3 values, tag} write-through.  No wait, no counter, no workgroup barrier.
@@ -155,7 +195,7 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
   float r[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {                      // values from n_live on are known to be zero (wave-uniform): not reduced
-    if (k < n_live) r[k] = op[k] == 0 ? wave_min(v[k]) : (op[k] == 1 ? wave_max(v[k]) : wave_sum(v[k]));
+    if (k < n_live) r[k] = op[k] == 0 ? MI_WMIN(v[k]) : (op[k] == 1 ? MI_WMAX(v[k]) : MI_WSUM(v[k]));
     else r[k] = 0.f;
   }
   unsigned before = 0;
@@ -319,13 +359,13 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     }
   }
 #pragma unroll
-  for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? wave_max(mm[k]) : wave_min(mm[k]);
-  if (NV == 1) sum[0] = wave_sum(sum[0]);
+  for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? MI_WMAX(mm[k]) : MI_WMIN(mm[k]);
+  if (NV == 1) sum[0] = MI_WSUM(sum[0]);
   if (NV >= 7) {
-    sum[0] = wave_sum(sum[0]); sum[1] = wave_sum(sum[1]);
+    sum[0] = MI_WSUM(sum[0]); sum[1] = MI_WSUM(sum[1]);
     if (rgb_sums) {                                    // else they are zero
 #pragma unroll
-      for (int k = 2; k < 5; ++k) sum[k] = wave_sum(sum[k]);
+      for (int k = 2; k < 5; ++k) sum[k] = MI_WSUM(sum[k]);
     }
   }
   unsigned finished = 0;
