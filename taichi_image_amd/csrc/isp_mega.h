@@ -173,6 +173,9 @@ MI_DEV float wsum(float v) {
 #undef MI_DPP_TREE
 #undef MI_DPP_STEP
 
+#ifndef MI_MEGA_EAGER_ROUND           /* measured: 47.0 us per frame against 44.2 - see barrier_fold */
+#define MI_MEGA_EAGER_ROUND 0
+#endif
 #ifndef MI_MEGA_ASM_REDUCE
 #define MI_MEGA_ASM_REDUCE 1
 #endif
@@ -265,6 +268,36 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       have[u][c] = (int)role * 128 + u * 64 + lane >= a.n_blocks || (NV >= 7 && c == NCH - 1 && !rgb_sums);
     }
   unsigned spins = 0;
+  // Stage 1: all records of this role.  The first round is served by the XCD's L2 (sc0: only the CU's own cache is
+  // bypassed): by now almost every record has been in memory for a while, the first wave of an XCD to ask brings a line
+  // in and the other 255 waves hit it - 2048 waves asking memory for 256 chunks each took 1.6 us.  A line the L2 holds
+  // from before its record was posted shows the old tag; such chunks, and every later round, bypass the L2 (sc1).
+  auto round = [&](auto auxc) {
+    constexpr int AUX = decltype(auxc)::value;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)((int)role * 128 + u * 64 + lane) * REC + 16u * c;
+        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, AUX);
+        v[u][c] = have[u][c] ? v[u][c] : t;
+      }
+    bool all = true;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) { have[u][c] = have[u][c] || v[u][c].w == tag; all = all && have[u][c]; }
+    return __builtin_amdgcn_ballot_w64(!all);
+  };
+  unsigned long long missing = ~0ull;
+#if MI_MEGA_EAGER_ROUND
+  // Measurement (off): one full round straight after the wave's own post, so that the waves that arrive LAST - which find
+  // every record there - are through after one round trip instead of their watch stage + L2 round + write-through round.
+  // 47.0 us per frame against 44.2: the early waves' extra round (2048 waves x 128 records while half the chip is still in
+  // its phase) costs far more than the late ones save - what the watch stage is there to prevent.
+  if (m.spin_limit > 1) missing = round(std::integral_constant<int, MI_MEGA_POLL_AUX>{});
+  if (missing != 0) {
+#endif
   // Stage 0: watch TWO typical records (lanes 0 and 1: the last block of the first half of the grid and the third last
   // block) until both are there - by then nine blocks in ten have posted.  2048 waves polling all records while most
   // blocks are still in their phase slow those down (their loads and posts queue behind the polls: posts took up to
@@ -294,28 +327,10 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       if ((spins += 4) > m.spin_limit) break;         // stage 1 raises the error
     }
   }
-  // Stage 1: all records of this role.  The first round is served by the XCD's L2 (sc0: only the CU's own cache is
-  // bypassed): by now almost every record has been in memory for a while, the first wave of an XCD to ask brings a line
-  // in and the other 255 waves hit it - 2048 waves asking memory for 256 chunks each took 1.6 us.  A line the L2 holds
-  // from before its record was posted shows the old tag; such chunks, and every later round, bypass the L2 (sc1).
-  auto round = [&](auto auxc) {
-    constexpr int AUX = decltype(auxc)::value;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)((int)role * 128 + u * 64 + lane) * REC + 16u * c;
-        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, AUX);
-        v[u][c] = have[u][c] ? v[u][c] : t;
-      }
-    bool all = true;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) { have[u][c] = have[u][c] || v[u][c].w == tag; all = all && have[u][c]; }
-    return __builtin_amdgcn_ballot_w64(!all);
-  };
-  unsigned long long missing = m.l2_first && m.spin_limit > 1 ? round(std::integral_constant<int, 1>{}) : ~0ull;
+  missing = m.l2_first && m.spin_limit > 1 ? round(std::integral_constant<int, 1>{}) : ~0ull;
+#if MI_MEGA_EAGER_ROUND
+  }
+#endif
   while (missing != 0) {
     // The budget is checked BEFORE a round.  A budget of 1 (tests/: mi_isp_whole_frame_set_poll_limit(1)) therefore means
     // "one round, straight after the wave's own post, no watch stage": the first block to arrive cannot find the others'
