@@ -173,6 +173,9 @@ MI_DEV float wsum(float v) {
 #undef MI_DPP_TREE
 #undef MI_DPP_STEP
 
+#ifndef MI_MEGA_LATE_SKIPS_L2         /* measured: 44.02 us per frame against 43.83 - see barrier_fold */
+#define MI_MEGA_LATE_SKIPS_L2 0
+#endif
 #ifndef MI_MEGA_EAGER_ROUND           /* measured: 47.0 us per frame against 44.2 - see barrier_fold */
 #define MI_MEGA_EAGER_ROUND 0
 #endif
@@ -304,6 +307,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   // 4.6 us instead of 1); two requests per wave and round do not.  Four polls in flight, a new one every 512 cycles.
   // Whichever blocks post last are deliberately NOT waited for here: stage 1 asks for whatever is still missing every
   // round, so a straggler's record is seen one round trip after it lands.
+  bool waited = false;                                // (wave-uniform)
   if (m.spin_limit > 1) {                             // (a budget of 1 - the fault test - polls at once)
     const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
     const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + 12u : INVALID_OFF;
@@ -317,6 +321,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     uint32_t q3 = ask();
     for (;;) {
       if (there(q0)) break;
+      waited = true;
       nap(); q0 = ask();
       if (there(q1)) break;
       nap(); q1 = ask();
@@ -327,7 +332,10 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       if ((spins += 4) > m.spin_limit) break;         // stage 1 raises the error
     }
   }
-  missing = m.l2_first && m.spin_limit > 1 ? round(std::integral_constant<int, 1>{}) : ~0ull;
+  // (Measurement, off: a wave that found both watched records at its first look - a late arrival - skipping the L2 round,
+  // on the theory that what its XCD's L2 holds of the records is mostly stale: 44.02 us per frame against 43.83.  The L2
+  // round pays for the late waves too.)
+  missing = m.l2_first && m.spin_limit > 1 && (waited || !MI_MEGA_LATE_SKIPS_L2) ? round(std::integral_constant<int, 1>{}) : ~0ull;
 #if MI_MEGA_EAGER_ROUND
   }
 #endif
