@@ -858,6 +858,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     // Only the sum of log(gray) needs the pixels again; the other statistics of the normalised image follow from the
     // raw ones of phase A (barrier_fold<1>).  gray(n) = (gray(x) - lo) * inv: see there.
     float sl0 = 0.f, sl1 = 0.f;
+    const float gwi0 = vgpr(0.299f * inv_s), gwi1 = vgpr(0.587f * inv_s), gwi2 = vgpr(0.114f * inv_s), gwc = vgpr(-lo_s * inv_s);
     static_for<0, ROWS>([&](auto rrc) {
       constexpr int RR = decltype(rrc)::value;
       prio_turn(RR, younger);
@@ -872,11 +873,15 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
           sl1 += hw_log2(fmaxf(gb, 1e-4f));
         });
 #else
-        // one logarithm per row: the product of its eight clamped gray values (Stats2::add8_gray)
+        // one logarithm per row: the product of its eight clamped gray values (Stats2::add8_gray).  The normalised gray in
+        // three instructions: (gray(x) - lo) * inv = (w0 inv) r + (w1 inv) g + (w2 inv) b - lo inv, the constant as the first
+        // fma's addend (differs from subtract-then-multiply by ~1e-7 relative; the scalars' contract is 1e-4)
         float c[8];
         static_for<0, 8>([&](auto kc) {
-          constexpr int K = decltype(kc)::value;
-          c[K] = fmaxf((gray_pk<K>(pk, gw0, gw1, gw2) - lo) * inv, 1e-4f);
+          constexpr int K = decltype(kc)::value, e = 3 * K;
+          const float a0 = fma_mix_h<e>(pk[e / 2], gwi0, gwc);
+          const float a1 = fma_mix_h<e + 1>(pk[(e + 1) / 2], gwi1, a0);
+          c[K] = fmaxf(fma_mix_h<e + 2>(pk[(e + 2) / 2], gwi2, a1), 1e-4f);
         });
         sl0 += hw_log2(((c[0] * c[1]) * (c[2] * c[3])) * ((c[4] * c[5]) * (c[6] * c[7])));
 #endif
