@@ -173,6 +173,12 @@ MI_DEV float wsum(float v) {
 #undef MI_DPP_TREE
 #undef MI_DPP_STEP
 
+// the normalisation of phases C and D (frames whose bounds are not (0, 1)) as one fma.  Measured on one box, unit / non-unit
+// frames: 44.05 / 50.13 us with it, 43.81 / 50.90 without - the frames it is not executed for pay 0.24 us for the other
+// arm's different register allocation.  Off: the headline is the unit frame.
+#ifndef MI_MEGA_NORM_FMA
+#define MI_MEGA_NORM_FMA 0
+#endif
 #ifndef MI_MEGA_LATE_SKIPS_L2         /* measured: 44.02 us per frame against 43.83 - see barrier_fold */
 #define MI_MEGA_LATE_SKIPS_L2 0
 #endif
@@ -853,6 +859,15 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   const bool unit = MI_CENSUS(lo_s == 0.f && inv_s == 1.f, true);
   // per-pixel operands live in VGPRs: a VALU instruction with an SGPR operand issues at half rate
   const float lo = vgpr(lo_s), inv = vgpr(inv_s);
+  // the normalisation of tonemap.py:13 for phases C and D as ONE fma: (x - lo) * inv = x * inv - lo * inv (two roundings
+  // instead of two, in another order: ~1e-7 relative, three orders below the f16 output's ulp); only frames whose bounds
+  // are not (0, 1) come here
+  const float nrm_c = vgpr(-lo_s * inv_s);
+#if MI_MEGA_NORM_FMA
+  auto norm_fma = [&](float x) __attribute__((always_inline)) { return clamp01(__builtin_fmaf(x, inv, nrm_c)); };
+#else
+  auto norm_fma = [&](float x) __attribute__((always_inline)) { (void)nrm_c; return norm01(x, lo, inv); };
+#endif
   if (!unit) {
     // ============================ phase B: the statistics for bounds other than (0, 1) ============================
     // Only the sum of log(gray) needs the pixels again; the other statistics of the normalised image follow from the
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     for (int k = 0; k < 8; ++k) {
       float x[3], o[3];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm01(t[3 * k + ch], lo, inv);
+      for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm_fma(t[3 * k + ch]);
       reinhard_px<CA0>(x, rk, o);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) q[3 * k + ch] = o[ch];
@@ -948,7 +963,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     for (int k = 0; k < 8; ++k) {
       float x[3];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm01(t[3 * k + ch], lo, inv);
+      for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm_fma(t[3 * k + ch]);
       const float ad = reinhard_adapt_ca0(x, rk);       // (the very function phase D evaluates again)
       const float xmin = fminf(x[0], fminf(x[1], x[2])), xmax = fmaxf(x[0], fmaxf(x[1], x[2]));
       vmin = fminf(vmin, reinhard_map(xmin, ad));
