@@ -260,6 +260,22 @@ int mi_isp_pipeline12_reinhard_whole_frame_batch(const uint8_t* const* packed_ho
 int mi_isp_workspace_check(void* ws_dev, int n_frames, int H, int W, int* failed_host, int* n_failed, void* stream);
 int mi_isp_whole_frame_faults(int clear);
 int mi_isp_whole_frame_set_poll_limit(unsigned polls);
+/* Round 4.  A block one of whose barriers has timed out polls every later barrier of the launch ONCE: it walks through
+ * the frames that are left (posting, so that nobody waits for it; marking the fault word of every frame whose records it
+ * does not find), so a launch that lost one block ends after about one poll budget (~0.1 - 0.2 s) instead of one budget
+ * per remaining barrier; mi_isp_workspace_check also wipes the barrier records of the frames it reports.
+ * mi_isp_whole_frame_set_sabotage(block): test hook - that block of every later launch does not post its record at the
+ *   first barrier of the launch's first frame (what a block that is not resident looks like to the others); -1 = off.
+ * The resident-grid kernels of the library (this one, the one-launch metering, the fused ISP tonemap) are launched in
+ * ONE order per device and process: a launch on another stream than the previous one waits for an event recorded behind
+ * that one. */
+int mi_isp_whole_frame_set_sabotage(int block);
+/* The one-launch update_metering (mi_isp_metering) when ITS barrier times out: state9 is left exactly as it was, the
+ * workspace's fault word is set and the device's metering mailbox word is stored to.
+ * mi_isp_metering_faults(clear): that mailbox word of the current device - a plain host read, no synchronisation.
+ * mi_isp_metering_set_poll_limit(polls): poll budget of the following launches (0 = default, ~1 s; tests use 1). */
+int mi_isp_metering_faults(int clear);
+int mi_isp_metering_set_poll_limit(unsigned polls);
 
 /* The same for n_frames independent frames, frame i on streams_host[i % n_streams]
  * (one frame per stream in flight); ws_dev holds n_frames consecutive workspaces;

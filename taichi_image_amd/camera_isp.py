@@ -37,6 +37,50 @@ def _typecheck(name, value, kinds, optional=False):
         raise TypeError(f"{name} must be {kinds}, got {type(value).__name__}")
 
 
+class MeteringTimeout(RuntimeError):
+    """The grid barrier of an earlier one-launch update_metering on this device timed out (something else held compute
+    units of the GPU for about a second).  That call left the metrics as they were - bounds folded from half of the blocks
+    must never enter the rolling average - so everything tone-mapped with them since is suspect.  Raised by the NEXT
+    update_metering / tonemap call (one host read of the device's mailbox, no synchronisation)."""
+
+
+def _version_of(t):
+    """torch's write counter of a tensor, None where there is none (inference tensors do not track one)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
+def _tag_subsample(rgb, sub, stride):
+    """Hang the dense metering subsample the load kernel left (`rgb[::stride, ::stride]`) on the image.  The tag is valid
+    while the image's version counter stands still: torch writes move it, the library's own in-place writes move it
+    explicitly (_written_in_place).  A tensor without a counter (created under torch.inference_mode(), as the reference's
+    bench does, bench/camera_isp.py:53) gets no tag - update_metering then gathers from the image itself."""
+    v = _version_of(rgb)
+    if v is not None:
+        rgb._mi_metering_sub = (sub, stride, v)
+
+
+def _valid_subsample(im, stride):
+    tag = getattr(im, "_mi_metering_sub", None)
+    if tag is None or tag[1] != stride or tag[2] != _version_of(im):
+        return None
+    return tag[0]
+
+
+def _written_in_place(images):
+    """The library has overwritten these images through their raw pointers (Reinhard pass 1 writes the mapped values p
+    back, camera_isp.py:211): what torch cannot see is made visible - the version counter moves (views and autograd see
+    a write) and a metering subsample taken before the write is dropped, so the next update_metering meters the
+    MUTATED image as the reference does (camera_isp.py:168-175 on the image of :211)."""
+    for im in images:
+        if getattr(im, "_mi_metering_sub", None) is not None:
+            del im._mi_metering_sub
+        if _version_of(im) is not None:
+            torch.autograd.graph.increment_version(im)
+
+
 def camera_isp(name: str, dtype=types.f32):
     """camera_isp.py:75-418: class factory specialised on the working dtype."""
     dtype = types.as_dtype(dtype)
@@ -59,6 +103,7 @@ def camera_isp(name: str, dtype=types.f32):
             image.data_ptr(), output.data_ptr(), H, W, dtype.code, metering.data_ptr(), float(gamma),
             float(intensity), float(light_adapt), float(color_adapt), interpolate.transform_code(transform),
             ws.data_ptr(), _native.stream_ptr(image.device)))
+        _written_in_place([image])
 
     def linear_kernel(image, output, metering, gamma, transform=interpolate.ImageTransform.none):
         """camera_isp.py:220-227."""
@@ -235,7 +280,7 @@ def camera_isp(name: str, dtype=types.f32):
                 src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value,
                 _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, 0.0,
                 sub.data_ptr(), st, _native.stream_ptr(self.device)))
-            rgb._mi_metering_sub = (sub, st, rgb._version)    # valid while nobody writes to the image through torch
+            _tag_subsample(rgb, sub, st)
             return rgb
 
         def load_packed12(self, image_data, ids_format=False):
@@ -291,7 +336,7 @@ def camera_isp(name: str, dtype=types.f32):
                 dtype.code, hd, wd, float(scale) if fused else 0.0, st, _native.stream_ptr(self.device)))
             if subs is not None:
                 for rgb, sub in zip(rgbs, subs):
-                    rgb._mi_metering_sub = (sub, st, rgb._version)
+                    _tag_subsample(rgb, sub, st)
             return rgbs
 
         def load_packed16(self, image_data):
@@ -324,14 +369,18 @@ def camera_isp(name: str, dtype=types.f32):
             stride = self.metering_stride
             # images that came out of load_packed12 / 16 carry their subsample: the same samples in the same order from a
             # dense buffer (stride 1) - identical results, no strided gather over the full-size images
-            tags = [getattr(im, "_mi_metering_sub", None) for im in images]
-            if all(t is not None and t[1] == stride and t[2] == im._version for t, im in zip(tags, images)):
-                images = [t[0] for t in tags]
+            subs = [_valid_subsample(im, stride) for im in images]
+            if all(s is not None for s in subs):
+                images = subs
                 H, W = images[0].shape[:2]
                 stride = 1
             ptrs = _native.ptr_array(images)
             L = _native.lib()
             stream = _native.stream_ptr(self.device)
+            with torch.cuda.device(self.device):
+                if L.mi_isp_metering_faults(1):
+                    raise MeteringTimeout("an earlier update_metering on this device timed out at its grid barrier: its "
+                                          "metrics were left unchanged and outputs tone-mapped with them are invalid")
             if self.process_group is None:
                 metering = prev.clone()
                 _native.check(L.mi_isp_metering(ptrs, len(images), H, W, stride, dtype.code,
@@ -390,6 +439,7 @@ def camera_isp(name: str, dtype=types.f32):
                 _native.ptr_array(images), _native.ptr_array(outputs), len(images), H, W, dtype.code,
                 self.metrics.data_ptr(), float(gamma), float(intensity), float(light_adapt), float(color_adapt),
                 interpolate.transform_code(self.transform), ws.data_ptr(), _native.stream_ptr(self.device)))
+            _written_in_place(images)
             return outputs
 
         def tonemap_reinhard_yuv420(self, images: List[torch.Tensor],
@@ -415,6 +465,7 @@ def camera_isp(name: str, dtype=types.f32):
                 _native.ptr_array(images), _native.ptr_array(outputs), len(images), H, W, dtype.code,
                 self.metrics.data_ptr(), float(gamma), float(intensity), float(light_adapt), float(color_adapt),
                 ws.data_ptr(), _native.stream_ptr(self.device)))
+            _written_in_place(images)
             return outputs
 
         def tonemap_linear(self, images: List[torch.Tensor], gamma: float = 1.0):

@@ -10,6 +10,7 @@
 #include "isp_mega.h"
 #include "isp_stream_resize.h"
 #include <mutex>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -404,31 +405,16 @@ static int pipeline_frame_cached(tile::Params p, int pattern, int work_dtype, fl
 // for at capture time): he must keep them off parallel branches, and replays of such a graph must not run beside
 // direct launches on other streams.  Other PROCESSES on the same GPU are invisible to all of this: a foreign kernel that
 // holds CUs makes the barrier time out - which is what the fault word, the mailbox and the multi-pass fallback are for.
+// Round 4: the order, its lock, the event and the mailbox page are those of ALL resident-grid kernels of the library
+// (ew::resident_order, isp_elementwise.h) - the one-launch metering kernel takes part in the same order.
 static struct {
-  std::mutex mu;
-  hipEvent_t done[16] = {};
-  hipStream_t last[16] = {};
-  bool has_last[16] = {};
   int n_cus[16] = {};
   int per_cu[4] = {-1, -1, -1, -1};          // per CFA pattern: the allocator's outcome differs per instantiation
-  unsigned* mailbox_host[16] = {};           // host-mapped word per device: the kernel stores here when a barrier times out
-  unsigned* mailbox_dev[16] = {};
   unsigned poll_limit = 0;                   // 0 = default
+  int sabotage_block = -1;                   // tests: this block never posts at barrier 0 of a launch's first frame
+  std::atomic<uint32_t> launches{0};         // the host's part of a launch's tag (isp_mega.h)
 } g_mega;
-
-// callers hold g_mega.mu
-static int mega_mailbox_locked(int dev) {
-  if (!g_mega.mailbox_host[dev]) {
-    void* h = nullptr;
-    MI_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
-    memset(h, 0, 64);
-    void* d = nullptr;
-    MI_HIP(hipHostGetDevicePointer(&d, h, 0));
-    g_mega.mailbox_host[dev] = static_cast<unsigned*>(h);
-    g_mega.mailbox_dev[dev] = static_cast<unsigned*>(d);
-  }
-  return 0;
-}
+static inline std::mutex& mega_mu() { return ew::resident_order().mu; }
 
 static bool mega_fits(const tile::Params& p, int work_dtype, const void* out, int out_dtype, int pattern, strm::SArgs& a) {
   if (work_dtype != MI_F16 || mi_dtype_size(out_dtype) > 2) return false;
@@ -436,7 +422,7 @@ static bool mega_fits(const tile::Params& p, int work_dtype, const void* out, in
   if (pattern < 0 || pattern > 3) return false;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
-  std::lock_guard<std::mutex> lock(g_mega.mu);
+  std::lock_guard<std::mutex> lock(mega_mu());
   if (g_mega.per_cu[pattern] < 0) g_mega.per_cu[pattern] = mega::blocks_per_cu(pattern);
   if (g_mega.n_cus[dev] == 0) {
     int n = 0;
@@ -460,23 +446,29 @@ static int mega_launch_frames(tile::Params p, strm::SArgs a, int pattern, float 
   MI_REQUIRE(dev >= 0 && dev < 16, "whole-frame kernel: device index %d out of range", dev);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cap);
-  std::lock_guard<std::mutex> lock(g_mega.mu);
-  if (int rc = mega_mailbox_locked(dev)) return rc;
+  std::lock_guard<std::mutex> lock(mega_mu());
+  ew::ResidentOrder& ord = ew::resident_order();
+  if (int rc = ew::resident_mailbox_locked(dev)) return rc;
   mega::MBatch mb = {};
   mb.m.s = a;
   mb.m.spin_limit = g_mega.poll_limit ? g_mega.poll_limit : 100000;   // ~100 ms of polling before a wave gives up
   mb.m.l2_first = 1;
   mb.m.poll_sleep = 0;                                       // extra 512-cycle naps between two polls (swept: 0 is best)
-  mb.m.mailbox = g_mega.mailbox_dev[dev];
+  mb.m.mailbox = ord.mailbox_dev[dev] + ew::MAILBOX_WHOLE_FRAME;
+  mb.m.sabotage_block = g_mega.sabotage_block;
 #ifdef MI_ISP_MEASURE
   if (getenv("MI_ISP_POLL_SLEEP")) mb.m.poll_sleep = (unsigned)atoi(getenv("MI_ISP_POLL_SLEEP"));
   if (getenv("MI_ISP_L2_FIRST")) mb.m.l2_first = (unsigned)atoi(getenv("MI_ISP_L2_FIRST"));
 #endif
   const bool direct = cap == hipStreamCaptureStatusNone;
-  if (direct && g_mega.has_last[dev] && g_mega.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, g_mega.done[dev], 0));
+  if (direct) { if (int rc = ew::resident_enter_locked(dev, s)) return rc; }
   const PassTimer tm0 = direct ? pass_timer(s, 1) : PassTimer{0, false, s};   // measurement aid: a launch as "pass 0"
   for (int i0 = 0; i0 < n; i0 += mega::MAX_BATCH) {
     mb.n_frames = n - i0 < mega::MAX_BATCH ? n - i0 : mega::MAX_BATCH;
+    // the host's part of the launch's tag: a block of an EARLIER launch that comes to life late (a foreign kernel held its
+    // CU) must not post records a later launch takes for its own (the workspace's own count covers graph replays, whose
+    // arguments are frozen)
+    mb.m.launch_id = g_mega.launches.fetch_add(1, std::memory_order_relaxed) + 1u;
     for (int i = 0; i < mb.n_frames; ++i) {
       mb.io[i].src = srcs[i0 + i];
       mb.io[i].dst = dsts[i0 + i];
@@ -488,11 +480,7 @@ static int mega_launch_frames(tile::Params p, strm::SArgs a, int pattern, float 
     if (int rc = mega::launch(mb, pattern, s)) return rc;
     if (int rc = tm.end(0)) return rc;
   }
-  if (direct) {
-    if (!g_mega.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_mega.done[dev], hipEventDisableTiming));
-    MI_HIP(hipEventRecord(g_mega.done[dev], s));
-    g_mega.last[dev] = s; g_mega.has_last[dev] = true;
-  }
+  if (direct) { if (int rc = ew::resident_leave_locked(dev, s)) return rc; }
   return 0;
 }
 
@@ -502,17 +490,27 @@ extern "C" size_t mi_isp_workspace_error_offset(int H, int W) {
 }
 
 extern "C" int mi_isp_whole_frame_set_poll_limit(unsigned polls) {
-  std::lock_guard<std::mutex> lock(g_mega.mu);
+  std::lock_guard<std::mutex> lock(mega_mu());
   g_mega.poll_limit = polls;
+  return 0;
+}
+
+// Test hook: block `block` of every later whole-frame launch does not post its record at barrier 0 of the launch's first
+// frame (-1: off) - the one fault a test can provoke that looks like a block which is not resident: everybody else waits
+// the FULL poll budget for it.
+extern "C" int mi_isp_whole_frame_set_sabotage(int block) {
+  std::lock_guard<std::mutex> lock(mega_mu());
+  g_mega.sabotage_block = block;
   return 0;
 }
 
 extern "C" int mi_isp_whole_frame_faults(int clear) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
-  std::lock_guard<std::mutex> lock(g_mega.mu);
-  if (!g_mega.mailbox_host[dev]) return 0;
-  volatile unsigned* mb = g_mega.mailbox_host[dev];
+  std::lock_guard<std::mutex> lock(mega_mu());
+  ew::ResidentOrder& ord = ew::resident_order();
+  if (!ord.mailbox_host[dev]) return 0;
+  volatile unsigned* mb = ord.mailbox_host[dev] + ew::MAILBOX_WHOLE_FRAME;
   const unsigned v = *mb;
   if (clear) *mb = 0;
   return (int)v;
@@ -535,6 +533,11 @@ extern "C" int mi_isp_workspace_check(void* ws_dev, int n_frames, int H, int W, 
       ++bad;
       v = 0;
       MI_HIP(hipMemcpy(w, &v, sizeof(v), hipMemcpyHostToDevice));   // the word is sticky in the kernel: cleared here
+      // and the barrier records of a failed frame are wiped: whatever a block that came to life late has left there can
+      // then never carry the tag of a later launch (a graph replay repeats the host's part of the tag)
+      float* partials = reinterpret_cast<float*>(static_cast<char*>(ws_dev) + (size_t)i * ws_bytes) + FP_COUNT;
+      const size_t stride = (size_t)mi_partial_cap(H, W);
+      MI_HIP(hipMemset(partials + (size_t)mega::MROW_BAR0 * stride, 0, (size_t)24 * stride * sizeof(float)));
     }
   }
   *n_failed = bad;
@@ -856,13 +859,10 @@ extern "C" int mi_isp_pipeline12_graph_launch(void* handle, void* stream) {
     MI_HIP(hipGetDevice(&dev));
     MI_REQUIRE(dev >= 0 && dev < 16, "pipeline12_graph_launch: device index %d out of range", dev);
     hipStream_t s = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lock(g_mega.mu);             // order, launch and record under one lock (see g_mega)
-    if (g_mega.has_last[dev] && g_mega.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, g_mega.done[dev], 0));
+    std::lock_guard<std::mutex> lock(mega_mu());             // order, launch and record under one lock (see g_mega)
+    if (int rc = ew::resident_enter_locked(dev, s)) return rc;
     MI_HIP(hipGraphLaunch(b->exec, s));
-    if (!g_mega.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_mega.done[dev], hipEventDisableTiming));
-    MI_HIP(hipEventRecord(g_mega.done[dev], s));
-    g_mega.last[dev] = s; g_mega.has_last[dev] = true;
-    return 0;
+    return ew::resident_leave_locked(dev, s);
   }
   MI_HIP(hipGraphLaunch(b->exec, (hipStream_t)stream));
   return 0;

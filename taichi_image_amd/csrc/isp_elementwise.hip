@@ -976,8 +976,11 @@ __global__ __launch_bounds__(EW_THREADS) void metering_kernel(const ew::PtrList 
 // payload (no arithmetic of this library produces one, so nothing a workspace may hold from earlier kernels matches it),
 // handed out by the host, different for every launch and phase.  The second meeting point is one-sided: only block 0
 // waits, folds the sums in fp64 and updates the state with the libm-grade finalize of the multi-launch path.
-// A block that does not see its peers within `spin_limit` polls sets the workspace's fault word (mi_isp_workspace_check)
-// and goes on: no hang.
+// A block that does not see its peers within `spin_limit` polls gives up - no hang - and the call FAILS as a whole: the
+// block marks its pass-2 record, block 0 (which also fails when its own wait runs out) then leaves state9 exactly as it
+// was, sets the workspace's fault word (mi_isp_workspace_check) and stores to the device's host-mapped mailbox
+// (mi_isp_metering_faults).  Bounds folded from the records that happened to be there must never be blended into the
+// rolling state: a moving average would carry them through every later call.
 // ---------------------------------------------------------------------------------------------
 constexpr int METER_MAX_BLOCKS = 256;
 constexpr int METER_THREADS = 1024;
@@ -991,7 +994,8 @@ struct MeterFused {
   float alpha, n_px;
   uint32_t tag;              // phase 0; phase 1 = tag + 1
   unsigned spin_limit;
-  unsigned* fault;
+  unsigned* fault;           // the workspace's fault word (mi_isp_workspace_check)
+  unsigned* mailbox;         // host-mapped word of the device (mi_isp_metering_faults): seen without a synchronisation
 };
 
 template <class T>
@@ -1000,7 +1004,9 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   __shared__ float red[METER_THREADS / 64][8];
   __shared__ float sh_b[2];
+  __shared__ unsigned sh_bad;              // this block gave up waiting for the bounds (its statistics are garbage)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) sh_bad = 0u;
   // grid = (blocks per image, images): the pointer list is indexed by blockIdx.y itself (a computed index sends the whole
   // argument struct through scratch)
   const int n_blocks = a.bpi * a.n_images, part = blockIdx.x, block = blockIdx.y * a.bpi + part;
@@ -1066,7 +1072,7 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
       }
       if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
       if (++spins > a.spin_limit) {
-        if (lane == 0) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) sh_bad = 1u;
         break;
       }
     }
@@ -1124,7 +1130,8 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
       // host memory, 13 - 27 us away (measured: the whole kernel took 34 us, 20 of them here).
       const int c = threadIdx.x;
       const float m0 = c == 0 ? t[0] : (c == 1 ? t[3] : t[6]);
-      const float m1 = c == 0 ? t[1] : (c == 1 ? t[4] : 0.f);
+      // (chunk 2's second word: 1 = this block never saw the bounds - what it posts here is not to be used)
+      const float m1 = c == 0 ? t[1] : (c == 1 ? t[4] : __builtin_bit_cast(float, sh_bad));
       const float m2 = c == 0 ? t[2] : (c == 1 ? t[5] : 0.f);
       const u4 mine = {__builtin_bit_cast(uint32_t, m0), __builtin_bit_cast(uint32_t, m1), __builtin_bit_cast(uint32_t, m2), a.tag + 1u};
       __builtin_amdgcn_raw_buffer_store_b128(mine, r1, (uint32_t)block * 48u + 16u * c, 0, 16);
@@ -1137,6 +1144,7 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
   {
     uint32_t w7[4][7];
     bool have[4];
+    bool failed = sh_bad != 0u;                              // (block 0's own wait for the bounds)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       have[j] = j * 64 + lane >= n_blocks;
@@ -1159,15 +1167,20 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
         if (!have[j] && t0[j].w == a.tag + 1u && t1[j].w == a.tag + 1u && t2[j].w == a.tag + 1u) {
           w7[j][0] = t0[j].x; w7[j][1] = t0[j].y; w7[j][2] = t0[j].z; w7[j][3] = t1[j].x; w7[j][4] = t1[j].y; w7[j][5] = t1[j].z;
           w7[j][6] = t2[j].x;
+          failed = failed || t2[j].y != 0u;
           have[j] = true;
         }
         all = all && have[j];
       }
       if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
-      if (++spins > a.spin_limit) {
-        if (lane == 0) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+      if (++spins > a.spin_limit) { failed = true; break; }
+    }
+    if (__builtin_amdgcn_ballot_w64(failed) != 0) {          // the state stays what it was; the failure is reported twice
+      if (lane == 0) {
+        __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.mailbox) __hip_atomic_store(a.mailbox, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      return;
     }
     float gmin = __builtin_inff(), gmax = -__builtin_inff();
     double sum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1726,10 +1739,8 @@ extern "C" int mi_isp_metering_combine_sums(const float* gathered, int n_ranks, 
 // One launch (metering_fused_kernel) when the group's blocks fit one per CU; MI_ISP_METERING_LAUNCHES=4 in the environment
 // forces the four-launch path (measurement, and the reference the fused path is tested against).
 static std::atomic<uint32_t> g_meter_launches{0};
-// Two of these kernels from two streams fit the chip side by side, three may each get a part of it and wait for the rest
-// forever (until the poll budget: fault word, no hang).  So the launches of a process are put in order per device: a launch
-// on another stream than the previous one waits for the event recorded behind that one.
-static struct { std::mutex mu; hipEvent_t done[16] = {}; hipStream_t last[16] = {}; } g_meter_order;
+// Its launches take part in the one order of the library's resident grids (ew::resident_order, isp_elementwise.h).
+static std::atomic<unsigned> g_meter_poll_limit{0};          // 0 = default; tests: mi_isp_metering_set_poll_limit
 static int metering_fused(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
                           float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done) {
   *done = false;
@@ -1756,11 +1767,13 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
   // a quiet NaN with a payload, two per launch (0x7FC00001 ...): see the kernel's head
   const uint32_t k = g_meter_launches.fetch_add(1, std::memory_order_relaxed);
   a.tag = 0x7FC00001u + 2u * (k % 0x1FFFFFu);
-  a.spin_limit = 2000000u;                                     // ~1 s of polling
+  const unsigned limit = g_meter_poll_limit.load(std::memory_order_relaxed);
+  a.spin_limit = limit ? limit - 1u : 2000000u;                // ~1 s of polling (a test's limit of 1: no second round)
   a.fault = reinterpret_cast<unsigned*>(fp) + 62;              // FP_ERROR (isp_mega.h): what mi_isp_workspace_check reads
-  std::lock_guard<std::mutex> lock(g_meter_order.mu);
-  if (!g_meter_order.done[dev]) MI_HIP(hipEventCreateWithFlags(&g_meter_order.done[dev], hipEventDisableTiming));
-  else if (g_meter_order.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, g_meter_order.done[dev], 0));
+  ew::ResidentOrder& ord = ew::resident_order();
+  std::lock_guard<std::mutex> lock(ord.mu);
+  if (int rc = ew::resident_enter_locked(dev, s)) return rc;
+  a.mailbox = ord.mailbox_dev[dev] + ew::MAILBOX_METERING;
   const int rc = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((metering_fused_kernel<T>), dim3(bpi, n_images), dim3(METER_THREADS), 0, s, a);
@@ -1768,11 +1781,62 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
     return 0;
   });
   if (rc) return rc;
-  MI_HIP(hipEventRecord(g_meter_order.done[dev], s));
-  g_meter_order.last[dev] = s;
+  if (int rc2 = ew::resident_leave_locked(dev, s)) return rc2;
   *done = true;
   return 0;
 }
+
+extern "C" int mi_isp_metering_set_poll_limit(unsigned polls) {
+  g_meter_poll_limit.store(polls, std::memory_order_relaxed);
+  return 0;
+}
+
+// The metering mailbox of the current device: non-zero when a one-launch update_metering gave up waiting for its
+// blocks since the word was last cleared (its state9 was left untouched).  A plain host read, no synchronisation.
+extern "C" int mi_isp_metering_faults(int clear) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  ew::ResidentOrder& ord = ew::resident_order();
+  std::lock_guard<std::mutex> lock(ord.mu);
+  if (!ord.mailbox_host[dev]) return 0;
+  volatile unsigned* mb = ord.mailbox_host[dev] + ew::MAILBOX_METERING;
+  const unsigned v = *mb;
+  if (clear) *mb = 0;
+  return (int)v;
+}
+
+namespace ew {
+ResidentOrder& resident_order() {
+  static ResidentOrder o;
+  return o;
+}
+int resident_mailbox_locked(int dev) {
+  ResidentOrder& o = resident_order();
+  if (!o.mailbox_host[dev]) {
+    void* h = nullptr;
+    MI_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
+    memset(h, 0, 64);
+    void* d = nullptr;
+    MI_HIP(hipHostGetDevicePointer(&d, h, 0));
+    o.mailbox_host[dev] = static_cast<unsigned*>(h);
+    o.mailbox_dev[dev] = static_cast<unsigned*>(d);
+  }
+  return 0;
+}
+int resident_enter_locked(int dev, hipStream_t s) {
+  ResidentOrder& o = resident_order();
+  if (int rc = resident_mailbox_locked(dev)) return rc;
+  if (o.has_last[dev] && o.last[dev] != s) MI_HIP(hipStreamWaitEvent(s, o.done[dev], 0));
+  return 0;
+}
+int resident_leave_locked(int dev, hipStream_t s) {
+  ResidentOrder& o = resident_order();
+  if (!o.done[dev]) MI_HIP(hipEventCreateWithFlags(&o.done[dev], hipEventDisableTiming));
+  MI_HIP(hipEventRecord(o.done[dev], s));
+  o.last[dev] = s; o.has_last[dev] = true;
+  return 0;
+}
+}  // namespace ew
 
 extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype,
                                float* state9, float alpha, void* ws, void* stream) {

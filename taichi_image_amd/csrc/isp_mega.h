@@ -31,10 +31,12 @@
 // and refuses larger frames (they take the multi-pass chain); a bounded poll turns a missing peer into an error flag
 // in the workspace (and a store to the device's host-mapped mailbox) instead of a hang.
 //
-// ASSUMPTION the barrier rests on: a 16-byte sc1 store to a 16-byte aligned address is observed WHOLE by a 16-byte sc1
-// load of that address - a poller never sees the new tag next to old values.  The ISA manual does not promise it; the
-// evidence is empirical (scripts/wf_soak.py: 2 000 000 frames compared bit for bit, tests/test_gpu_fullsize.py::
-// test_whole_frame_kernel_is_deterministic).  A torn record would show as a frame that differs from its first run.
+// Rounds 2 and 3 rested on an ASSUMPTION: a 16-byte sc1 store to a 16-byte aligned address is observed WHOLE by a 16-byte
+// sc1 load of that address - a poller never sees the new tag next to old values.  The ISA manual does not promise it (the
+// evidence was empirical: 2 000 000 frames compared bit for bit).  Round 4: the records check THEMSELVES.  The fourth word
+// of a chunk is tag ^ rec_hash(x, y, z); a poller accepts a chunk only when w ^ rec_hash(x, y, z) == tag, so a chunk made
+// of old and new words is - like a chunk that has not been posted yet - simply asked for again.  A torn read is now a
+// detected condition (one more round trip) instead of a silently wrong frame.
 //
 // Round 3: ONE launch walks through a batch of frames (MBatch): the grid stays resident, the counters in LDS run on over
 // the frames, a wave that has stored its rows of frame f goes straight on to frame f + 1.
@@ -109,7 +111,7 @@ constexpr int ROW_U4 = 64 * 3;       // one f16 row of a wave: 64 lanes x 3 x 16
 constexpr int REC = MI_MEGA_REC;
 constexpr int MROW_BAR0 = strm::MEGA_ROW_BASE, MROW_BAR1 = MROW_BAR0 + 8, MROW_BAR2 = MROW_BAR1 + 8;
 static_assert(MROW_BAR2 + 8 <= strm::PART_ROWS, "the whole-frame kernel's rows must fit the workspace");
-static_assert(REC >= 48 && REC % 16 == 0, "three 16-byte chunks per record");
+static_assert(REC >= 64 && REC % 16 == 0, "three 16-byte chunks and the beacon per record");
 constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
 
 // cache policy bits of the barrier's posts and polls.  16 = sc1.  Measured per frame (unit / non-unit): posts 17 (sc0 sc1)
@@ -121,6 +123,17 @@ constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside Fra
 #ifndef MI_MEGA_POLL_AUX
 #define MI_MEGA_POLL_AUX 16
 #endif
+// check word of a record chunk: two multiplies and a shift (a torn chunk passes only if the words that differ collide
+// in 32 bits of a multiplicative hash)
+MI_DEV uint32_t rec_hash(uint32_t x, uint32_t y, uint32_t z) {
+#ifdef MI_MEGA_NO_HASH
+  return 0u;
+#endif
+  uint32_t h = ((x * 0x9E3779B1u) ^ y) * 0x85EBCA6Bu ^ z;
+  return h ^ (h >> 15);
+}
+constexpr uint32_t BEACON_OFF = 48u + 12u;   // fourth chunk of a record: {0, 0, 0, tag} in the clear, for the watch stage only
+
 struct MArgs {
   SArgs s;                           // geometry and parameters shared by the frames of a launch (s.t.src / dst / fp / partials
                                      // and s.fp_w are per frame: FrameIO)
@@ -128,6 +141,8 @@ struct MArgs {
   unsigned poll_sleep;               // units of 512 cycles between two polls of the partial rows
   unsigned l2_first;                 // the first round of a fold reads through the L2
   unsigned* mailbox;                 // host-mapped word of the device: stored to when a barrier times out (no sync needed to see it)
+  uint32_t launch_id;                // the host's count of whole-frame launches: part of the tag (see the frame loop)
+  int sabotage_block;                // tests: this block does not post at barrier 0 of the launch's first frame (-1: none)
 };
 
 // One launch takes a BATCH of frames (same size and parameters), one after the other: the grid stays resident, a wave
@@ -205,7 +220,8 @@ MI_DEV float wsum(float v) {
 // {3 values, tag} write-through.  No wait, no counter, no workgroup barrier.
 template <int NV>
 MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (*red)[16], unsigned* arrived,
-                              float* area, int stride, int block, int wave, int lane, uint32_t tag, int n_live = NV) {
+                              float* area, int stride, int block, int wave, int lane, uint32_t tag, int n_live = NV,
+                              bool withhold = false) {
   constexpr int NCH = (NV + 2) / 3;
   float r[NV];
 #pragma unroll
@@ -222,7 +238,7 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
   before = __builtin_amdgcn_readfirstlane(before);
   if ((before & (WAVES - 1)) == WAVES - 1) {          // wave-uniform: this wave arrived last (the count runs on over the phases)
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    u4 mine = {0u, 0u, 0u, tag};                       // lane c holds chunk c
+    u4 mine = {0u, 0u, 0u, tag};                       // lane c holds chunk c, lane NCH the beacon {0, 0, 0, tag}
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       float x = red[0][k];
@@ -234,7 +250,9 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
       if (lane == k / 3) mine[k % 3] = __builtin_bit_cast(uint32_t, x);
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(area, 0, (int)((size_t)8 * stride * sizeof(float)), 0x00020000);
-    const uint32_t off = lane < NCH ? (uint32_t)block * REC + 16u * lane : INVALID_OFF;
+    if (lane < NCH) mine.w = tag ^ rec_hash(mine.x, mine.y, mine.z);
+    const uint32_t off = withhold ? INVALID_OFF
+                                  : (lane < NCH ? (uint32_t)block * REC + 16u * lane : (lane == NCH ? (uint32_t)block * REC + 48u : INVALID_OFF));
     __builtin_amdgcn_raw_buffer_store_b128(mine, rs, off, 0, MI_MEGA_POST_AUX);   // aux 16 = sc1: write-through, visible to the other XCDs
   }
 }
@@ -246,6 +264,7 @@ struct FoldLds {
   float mm[WAVES][4];
   float sum[WAVES][5];
   float keep[7];                          // barrier 0's totals of the speculative statistics, for barrier 1 (bounds other than (0, 1))
+  unsigned faulted;                       // latched by the first wave of the block whose poll budget runs out (barrier_fold: budget)
 };
 
 // Wait for the barrier whose records live in `area` and derive the scalars of the next phase.  Every wave of the block
@@ -280,6 +299,14 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       have[u][c] = (int)role * 128 + u * 64 + lane >= a.n_blocks || (NV >= 7 && c == NCH - 1 && !rgb_sums);
     }
   unsigned spins = 0;
+  // The poll budget.  Once a wave of this block has run out of it (FoldLds::faulted, latched for the rest of the launch)
+  // the block's budget is ONE round per barrier: the launch is lost for it, and it walks through what is left - posting,
+  // so that nobody waits for it, and marking the fault word of every frame whose records it does not find - instead of
+  // spending ~100 ms again at each of the 3 x 64 barriers to come (round 3 did: one disturbance at launch turned a 2.8 ms
+  // launch into tens of seconds of a spinning resident grid).  Leaving the launch altogether was built first: an exit from
+  // the middle of the frame loop cost 24 - 72 spilled registers in every instantiation.
+  const unsigned budget = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.faulted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                              ? 1u : m.spin_limit;
   // Stage 1: all records of this role.  The first round is served by the XCD's L2 (sc0: only the CU's own cache is
   // bypassed): by now almost every record has been in memory for a while, the first wave of an XCD to ask brings a line
   // in and the other 255 waves hit it - 2048 waves asking memory for 256 chunks each took 1.6 us.  A line the L2 holds
@@ -298,7 +325,10 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) { have[u][c] = have[u][c] || v[u][c].w == tag; all = all && have[u][c]; }
+      for (int c = 0; c < NCH; ++c) {
+        have[u][c] = have[u][c] || (v[u][c].w ^ rec_hash(v[u][c].x, v[u][c].y, v[u][c].z)) == tag;
+        all = all && have[u][c];
+      }
     return __builtin_amdgcn_ballot_w64(!all);
   };
   unsigned long long missing = ~0ull;
@@ -307,7 +337,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   // every record there - are through after one round trip instead of their watch stage + L2 round + write-through round.
   // 47.0 us per frame against 44.2: the early waves' extra round (2048 waves x 128 records while half the chip is still in
   // its phase) costs far more than the late ones save - what the watch stage is there to prevent.
-  if (m.spin_limit > 1) missing = round(std::integral_constant<int, MI_MEGA_POLL_AUX>{});
+  if (budget > 1) missing = round(std::integral_constant<int, MI_MEGA_POLL_AUX>{});
   if (missing != 0) {
 #endif
   // Stage 0: watch TWO typical records (lanes 0 and 1: the last block of the first half of the grid and the third last
@@ -317,9 +347,9 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   // Whichever blocks post last are deliberately NOT waited for here: stage 1 asks for whatever is still missing every
   // round, so a straggler's record is seen one round trip after it lands.
   bool waited = false;                                // (wave-uniform)
-  if (m.spin_limit > 1) {                             // (a budget of 1 - the fault test - polls at once)
+  if (budget > 1) {                             // (a budget of 1 - the fault test - polls at once)
     const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
-    const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + 12u : INVALID_OFF;
+    const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + BEACON_OFF : INVALID_OFF;
     const bool idle = !(lane < 2 && watch >= 0);
     auto ask = [&]() { return __builtin_amdgcn_raw_buffer_load_b32(prs, off, 0, MI_MEGA_POLL_AUX); };
     auto nap = [&]() { for (unsigned z = 0; z <= m.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8); };
@@ -338,13 +368,13 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       nap(); q2 = ask();
       if (there(q3)) break;
       nap(); q3 = ask();
-      if ((spins += 4) > m.spin_limit) break;         // stage 1 raises the error
+      if ((spins += 4) > budget) break;         // stage 1 raises the error
     }
   }
   // (Measurement, off: a wave that found both watched records at its first look - a late arrival - skipping the L2 round,
   // on the theory that what its XCD's L2 holds of the records is mostly stale: 44.02 us per frame against 43.83.  The L2
   // round pays for the late waves too.)
-  missing = m.l2_first && m.spin_limit > 1 && (waited || !MI_MEGA_LATE_SKIPS_L2) ? round(std::integral_constant<int, 1>{}) : ~0ull;
+  missing = m.l2_first && budget > 1 && (waited || !MI_MEGA_LATE_SKIPS_L2) ? round(std::integral_constant<int, 1>{}) : ~0ull;
 #if MI_MEGA_EAGER_ROUND
   }
 #endif
@@ -352,10 +382,12 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     // The budget is checked BEFORE a round.  A budget of 1 (tests/: mi_isp_whole_frame_set_poll_limit(1)) therefore means
     // "one round, straight after the wave's own post, no watch stage": the first block to arrive cannot find the others'
     // records there, so at least one block reports the fault - deterministically.
-    if (spins >= m.spin_limit) {                      // a peer is not resident: give up loudly instead of hanging
+    if (spins >= budget) {                      // a peer is not resident: give up loudly instead of hanging
       if (lane == 0) {
         __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (m.mailbox) __hip_atomic_store(m.mailbox, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // latched: from the next barrier on the block's budget is one round
+        __hip_atomic_store(&fl.faulted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       break;
     }
@@ -609,7 +641,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   __shared__ unsigned arrived;
   __shared__ FoldLds fl;
   if (threadIdx.x < 4) { fl.ticket[threadIdx.x] = 0; fl.done[threadIdx.x] = 0; fl.flag[threadIdx.x] = 0; }
-  if (threadIdx.x == 0) arrived = 0;
+  if (threadIdx.x == 0) { arrived = 0; fl.faulted = 0; }
   if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = 0.f;
 
   // Where a wave works.  Derived twice: here for the first frame's first loads, and again at the top of every frame from
@@ -707,7 +739,12 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   float* const partials = ws + FP_COUNT;
   const __amdgpu_buffer_rsrc_t rsrc = src_rsrc(io.src);
   const uint32_t epoch = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(ws)[FP_EPOCH]);
-  const uint32_t tag = epoch + 1u == 0u ? 1u : epoch + 1u;     // never 0: a zero-filled workspace matches no launch
+  // The tag of this launch's records in this workspace: the workspace's own launch count (it covers graph replays, whose
+  // kernel arguments are frozen) mixed with the host's launch count (it tells two launches apart even for a block that
+  // came to life after block 0 of ITS launch had advanced the epoch - such a block now posts records no launch will ever
+  // take for its own).  Never 0: a zero-filled workspace matches no launch.
+  const uint32_t tag_ = m.launch_id * 0x9E3779B1u + epoch + 1u;
+  const uint32_t tag = tag_ == 0u ? 1u : tag_;
   MI_MSTAMP(0);
 #ifdef MI_STREAM_STAMPS
   unsigned* st_ = reinterpret_cast<unsigned*>(partials + (size_t)PART_ROWS * p.part_stride) + g * 16;
@@ -828,7 +865,8 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }
     const float v9[9] = {vmin, vmax, st.gmin, st.gmax, st.slog, st.sgray, st.s0, st.s1, st.s2};
     const int op[9] = {0, 1, 0, 1, 2, 2, 2, 2, 2};
-    block_reduce_post<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane, tag, want_rgb ? 9 : 6);
+    block_reduce_post<9>(v9, op, red, &arrived, rows_bounds, p.part_stride, blockIdx.x, wave, lane, tag, want_rgb ? 9 : 6,
+                         f == 0 && m.sabotage_block == (int)blockIdx.x);
   }
 
   // the resident row RR: packed, and as 24 fp32 values

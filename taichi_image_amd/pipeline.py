@@ -55,13 +55,89 @@ def _failed_frames(ws, n_frames, H, W, device):
     return [i for i in range(n_frames) if failed[i]]
 
 
-def _report(frames_lost, on_timeout, what):
+def _report(frames_lost, on_timeout, what, later=False):
     msg = (f"{what}: a grid barrier of the whole-frame kernel timed out for frame(s) {list(frames_lost)} - something else "
-           "held compute units of this GPU; the frames were re-issued through the multi-pass chain and are valid now")
+           "held compute units of this GPU; the frames were re-issued through the multi-pass chain and are valid now"
+           + (" (they were NOT while the calls that followed them ran: this is reported at the first call after the fault)"
+              if later else ""))
     if on_timeout == "raise":
         raise WholeFrameTimeout(msg, frames_lost)
     import warnings
     warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def _multi_pass(packed, out, H, W, ids_format, pattern, ccm, work, odt, params, ws):
+    # an output dtype other than the work dtype: scratch for the work-dtype image between the passes (the
+    # caching allocator makes this cheap; without it the library re-derives the image in every pass)
+    work_image = None if odt.code == work.code else torch.empty((H, W, 3), dtype=work.torch, device=packed.device)
+    g, i, la, ca = params
+    _native.check(_native.lib().mi_isp_pipeline12_reinhard(
+        packed.data_ptr(), out.data_ptr(), None if work_image is None else work_image.data_ptr(),
+        H, W, int(bool(ids_format)), pattern.value, ccm, work.code, odt.code, g, i, la, ca, ws.data_ptr(),
+        _native.stream_ptr(packed.device)))
+
+
+# Whole-frame launches of pipeline12_reinhard that have not been looked at yet, per device, oldest first: weak references
+# to the caller's tensors (a frame nobody holds any more needs no repair) and what it takes to re-issue the call.
+_pending: dict = {}
+_PENDING_MAX = 1024
+# The mailbox is one word per device, shared by everything that launches the whole-frame kernel there (this function's
+# deferred path, every BatchPipeline).  Who finds it set looks at his OWN fault words (sticky, per workspace) and clears the
+# mailbox only when the fault was his; otherwise he remembers that the set state belongs to somebody else (and, for the
+# deferred path, checks his own launches synchronously until the owner has cleared it).
+_not_mine: dict = {}
+
+
+def _mailbox_set(device, owner):
+    """One host read.  False also while the set state is known to be somebody else's."""
+    with torch.cuda.device(device):
+        v = _native.lib().mi_isp_whole_frame_faults(0)
+    if not v:
+        _not_mine.pop((device.index or 0, owner), None)
+        return False
+    return not _not_mine.get((device.index or 0, owner), False)
+
+
+def _mailbox_settle(device, owner, mine):
+    if mine:
+        with torch.cuda.device(device):
+            _native.lib().mi_isp_whole_frame_faults(1)
+    else:
+        _not_mine[(device.index or 0, owner)] = True
+
+
+def check_pending(device=None, on_timeout="fallback"):
+    """The deferred check of pipeline12_reinhard's default path, on demand: ONE host read of the device's fault mailbox
+    (no synchronisation).  Only when it is set: synchronise, find the calls whose workspace carries the fault word and
+    re-issue them through the multi-pass chain on the current stream; then warn (on_timeout="fallback") or raise
+    WholeFrameTimeout (="raise").  Returns the number of frames re-issued.  Call it at a point where you synchronise
+    anyway and BEFORE consuming outputs when you cannot afford to find out one call later."""
+    import weakref  # noqa: F401
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = device.index or 0
+    if not _mailbox_set(device, "single"):
+        return 0
+    with torch.cuda.device(device):
+        torch.cuda.synchronize(device)
+        entries = _pending.pop(key, [])
+        bad_ws, redo, gone = {}, [], 0
+        for n, (rp, ro, args, ws) in enumerate(entries):
+            wkey = ws.data_ptr()
+            if wkey not in bad_ws:
+                bad_ws[wkey] = bool(_failed_frames(ws, 1, args[0], args[1], device))
+            if bad_ws[wkey]:
+                packed, out = rp(), ro()
+                if packed is None or out is None:
+                    gone += 1
+                else:
+                    redo.append((n, packed, out, args, ws))
+        _mailbox_settle(device, "single", any(bad_ws.values()))
+        for n, packed, out, args, ws in redo:
+            _multi_pass(packed, out, *args, ws)
+        if redo or gone:
+            _report([n for n, *_ in redo], on_timeout, "pipeline12_reinhard", later=True)
+        return len(redo)
 
 
 def pipeline12_reinhard(packed, pattern=BayerPattern.RGGB, ids_format=False, correct_colors=None,
@@ -71,45 +147,56 @@ def pipeline12_reinhard(packed, pattern=BayerPattern.RGGB, ids_format=False, cor
 
     whole_frame: True = the single-launch kernel (csrc/isp_mega.h; f16 work dtype, u8 / u16 / f16 output, frames up to
     4096 x 3072 on MI355X), False = the multi-pass chain, None (default) = the single-launch kernel whenever it takes the
-    frame.  Same results within the tonemap tolerance.  The single-launch kernel needs the GPU to itself: when a foreign
-    kernel keeps its blocks from being resident together its barriers time out and the frame is invalid.
-    check: True = synchronise, read the frame's fault word and, if it is set, re-issue the frame through the multi-pass
-    chain (the result is then always valid; on_timeout="fallback" warns, "raise" raises WholeFrameTimeout after the
-    re-issue); False = no synchronisation (BatchPipeline.check, or mi_isp_whole_frame_faults, tell later).  Default:
-    True when the kernel was chosen automatically, False when whole_frame=True was asked for."""
+    frame (never inside a stream capture: a captured launch can be neither ordered nor checked).  Same results within
+    the tonemap tolerance.  The single-launch kernel needs the GPU to itself: when a foreign kernel keeps its blocks from
+    being resident together its barriers time out and the frame is invalid.
+    check: how that is found out.
+      "deferred" (the default when the kernel was chosen automatically): NO synchronisation.  Every call first reads the
+          device's host-mapped fault mailbox (a plain host read); when an earlier launch has timed out, the calls since
+          the last look are checked and the lost frames re-issued through the multi-pass chain - reported (warning, or
+          WholeFrameTimeout with on_timeout="raise") at that FOLLOWING call, or at check_pending(), whichever comes first.
+          A frame consumed in between was invalid: call check_pending() behind your own synchronisation when that matters.
+      True: synchronise right after the launch, re-issue at once (the result is always valid on return).
+      False (the default with whole_frame=True): nothing; BatchPipeline.check / mi_isp_whole_frame_faults tell later."""
+    import weakref
     H, W = _check_packed(packed)
     work, odt = types.as_dtype(work_dtype), types.as_dtype(dtype)
     if out is None:
         out = torch.empty((H, W, 3), dtype=odt.torch, device=packed.device)
     ws = _native.workspace(H, W, packed.device)
+    capturing = torch.cuda.is_current_stream_capturing()
     if check is None:
-        check = whole_frame is None
+        check = "deferred" if whole_frame is None else False
     if whole_frame is None:
-        whole_frame = _auto_whole_frame(H, W, work, odt, ids_format)
-
-    def multi_pass():
-        # an output dtype other than the work dtype: scratch for the work-dtype image between the passes (the
-        # caching allocator makes this cheap; without it the library re-derives the image in every pass)
-        work_image = None if odt.code == work.code else torch.empty((H, W, 3), dtype=work.torch, device=packed.device)
-        _native.check(_native.lib().mi_isp_pipeline12_reinhard(
-            packed.data_ptr(), out.data_ptr(), None if work_image is None else work_image.data_ptr(),
-            H, W, int(bool(ids_format)), pattern.value, _native.ccm_arg(correct_colors),
-            work.code, odt.code, float(gamma), float(intensity), float(light_adapt), float(color_adapt), ws.data_ptr(),
-            _native.stream_ptr(packed.device)))
+        whole_frame = not capturing and _auto_whole_frame(H, W, work, odt, ids_format)
+    if capturing:
+        check = False                                 # (no host-side look is possible at capture time)
+    ccm = _native.ccm_arg(correct_colors)
+    params = (float(gamma), float(intensity), float(light_adapt), float(color_adapt))
+    args = (H, W, ids_format, pattern, ccm, work, odt, params)
+    if check == "deferred":
+        check_pending(packed.device, on_timeout)      # one host read; repairs and reports what an EARLIER call lost
 
     if whole_frame:
         assert work.code == types.f16.code, "the whole-frame kernel works in f16"
         _native.check(_native.lib().mi_isp_pipeline12_reinhard_whole_frame(
-            packed.data_ptr(), out.data_ptr(), H, W, int(bool(ids_format)), pattern.value,
-            _native.ccm_arg(correct_colors), odt.code, float(gamma), float(intensity), float(light_adapt),
-            float(color_adapt), ws.data_ptr(), _native.stream_ptr(packed.device)))
-        if check and _failed_frames(ws, 1, H, W, packed.device):
-            with torch.cuda.device(packed.device):
-                _native.lib().mi_isp_whole_frame_faults(1)
-            multi_pass()
-            _report([0], on_timeout, "pipeline12_reinhard")
+            packed.data_ptr(), out.data_ptr(), H, W, int(bool(ids_format)), pattern.value, ccm, odt.code, *params,
+            ws.data_ptr(), _native.stream_ptr(packed.device)))
+        if check == "deferred" and _not_mine.get((packed.device.index or 0, "single"), False):
+            check = True                              # the mailbox is held by somebody else's fault: look at our own word
+        if check is True:
+            if _failed_frames(ws, 1, H, W, packed.device):
+                with torch.cuda.device(packed.device):
+                    _native.lib().mi_isp_whole_frame_faults(1)
+                _multi_pass(packed, out, *args, ws)
+                _report([0], on_timeout, "pipeline12_reinhard")
+        elif check == "deferred":
+            q = _pending.setdefault(packed.device.index or 0, [])
+            if len(q) >= _PENDING_MAX:
+                del q[:_PENDING_MAX // 2]
+            q.append((weakref.ref(packed), weakref.ref(out), args, ws))
         return out
-    multi_pass()
+    _multi_pass(packed, out, *args, ws)
     return out
 
 
@@ -117,7 +204,14 @@ class BatchPipeline:
     """Independent frames, one frame per HIP stream in flight (BASELINE config 4 on one GPU).
 
     Owns `n_streams` streams, the per-frame workspaces and the output tensors so that a step is
-    one C call issuing 4 launches per frame (7 on the recompute variant) with no allocation on the way."""
+    one C call issuing 4 launches per frame (7 on the recompute variant) with no allocation on the way.
+
+    With the whole-frame kernel (the default for frames it takes) a batch is ONE asynchronous launch, and its outputs are
+    valid only if no grid barrier timed out (something else held compute units of the GPU).  Before CONSUMING the outputs
+    of a batch either call check() (synchronises, repairs lost frames through the multi-pass chain) or, behind a
+    synchronisation of your own, faulted() (one host read of the device's mailbox, no synchronisation: False = every
+    whole-frame launch of this process on the device so far was complete).  __call__ looks at the mailbox too and
+    repairs the PREVIOUS batch before it issues the next - too late for a caller who has consumed it already."""
 
     def __init__(self, n_frames, H, W, device, n_streams=2, pattern=BayerPattern.RGGB, ids_format=False,
                  correct_colors=None, work_dtype=types.f16, dtype=types.f16, gamma=1.0, intensity=1.0,
@@ -153,6 +247,7 @@ class BatchPipeline:
         self._graph, self._graph_key = None, None
 
     def __del__(self):
+        _not_mine.pop(((self.device.index or 0) if hasattr(self, "device") else 0, id(self)), None)
         g = getattr(self, "_graph", None)
         if g is not None:
             try:
@@ -167,9 +262,7 @@ class BatchPipeline:
         for f in frames:
             assert _check_packed(f) == (self.H, self.W)
         if self.whole_frame:
-            with torch.cuda.device(self.device):
-                pending = _native.lib().mi_isp_whole_frame_faults(0)
-            if pending and self._last_frames is not None:
+            if self._last_frames is not None and _mailbox_set(self.device, id(self)):
                 self.check()
             self._last_frames = list(frames)
         if self.use_graph and not eager:
@@ -192,6 +285,14 @@ class BatchPipeline:
             return self.outputs
         return self._issue(frames)
 
+    def faulted(self):
+        """Has any whole-frame launch on this device timed out since the mailbox was last cleared?  A host read; meaningful
+        for a batch once the caller has synchronised with it."""
+        if not self.whole_frame:
+            return False
+        with torch.cuda.device(self.device):
+            return bool(_native.lib().mi_isp_whole_frame_faults(0))
+
     def check(self, frames=None):
         """Synchronise and make sure every output of the last batch is valid: frames whose fault word is set (a barrier
         of the whole-frame kernel timed out) are re-issued through the multi-pass chain; returns their indices
@@ -202,7 +303,8 @@ class BatchPipeline:
             if not self.whole_frame:
                 return []
             lost = _failed_frames(self.ws, self.n_frames, self.H, self.W, self.device)
-            _native.lib().mi_isp_whole_frame_faults(1)
+            if _native.lib().mi_isp_whole_frame_faults(0):
+                _mailbox_settle(self.device, id(self), bool(lost))
             if lost:
                 assert frames is not None, "check(): pass the frames of the batch that was lost"
                 g, i, la, ca = self.params

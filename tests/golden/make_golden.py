@@ -61,6 +61,7 @@ def build():
     g["isp_u8"], g["isp_after"] = u8, after
     g["isp_linear_u8"] = O.linear_isp(im, m2, 0.8)
     g["resize_f32"] = O.resize_bilinear(img, (30, 20), 0.46875)
+    g["scene_f32"] = img                     # the source of resize_f32 (round 4: the GPU test reads the file alone)
     return g
 
 

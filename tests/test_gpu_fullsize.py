@@ -329,9 +329,19 @@ def test_whole_frame_timeout_is_reported_and_repaired(ti, dev, scenes):
             pipeline12_reinhard(frames[0], out=out, whole_frame=True, check=True, on_timeout="raise")
         assert ei.value.frames == (0,)
         assert_close(out.cpu().numpy(), refs[0], "re-issued frame (raise)")
+        # the default (auto-selected kernel): NO synchronisation; the fault is found by the FOLLOWING call's look at the
+        # device's mailbox (a host read), which re-issues the lost frame and reports it
+        from taichi_image_amd.pipeline import check_pending
+        got = pipeline12_reinhard(frames[1])
+        torch.cuda.synchronize()                                  # (so that the kernel has run and stored to the mailbox)
         with pytest.warns(RuntimeWarning, match="timed out"):
-            got = pipeline12_reinhard(frames[1])                  # the default: auto-selected, checked, repaired
-        assert_close(got.cpu().numpy(), refs[1], "re-issued frame (default)")
+            got2 = pipeline12_reinhard(frames[0])                 # repairs `got`; its own launch is lost in turn ...
+        torch.cuda.synchronize()
+        with pytest.raises(WholeFrameTimeout):
+            check_pending(dev, on_timeout="raise")                # ... and repaired here, on demand
+        assert check_pending(dev) == 0                            # nothing is left pending
+        assert_close(got.cpu().numpy(), refs[1], "re-issued frame (default, repaired by the following call)")
+        assert_close(got2.cpu().numpy(), refs[0], "re-issued frame (default, repaired by check_pending)")
         # unchecked: the call returns, the mailbox tells without a synchronisation of the caller's
         pipeline12_reinhard(frames[0], out=out, whole_frame=True)
         torch.cuda.synchronize()
@@ -355,6 +365,49 @@ def test_whole_frame_timeout_is_reported_and_repaired(ti, dev, scenes):
     again = pipeline12_reinhard(frames[0], whole_frame=True)
     torch.cuda.synchronize()
     assert _error_word(ti, 3072, 4096, dev) == 0 and torch.equal(again, good)
+    # the default path once more, undisturbed: asynchronous, nothing to report at the next look
+    again = pipeline12_reinhard(frames[0])
+    torch.cuda.synchronize()
+    from taichi_image_amd.pipeline import check_pending
+    assert check_pending(dev) == 0 and torch.equal(again, good)
+
+
+def test_whole_frame_launch_that_lost_a_block_ends_soon(ti, dev, rng):
+    """One block that never posts (what a block that is not resident looks like to the others) must cost ONE poll budget
+    (~0.1 s), not one per barrier that is left: a 64-frame launch has 192 of them (round 3: ~19 s of a spinning resident
+    grid).  Every lost frame carries its fault word and check() repairs the batch."""
+    import time
+    from taichi_image_amd import _native
+    from taichi_image_amd.pipeline import BatchPipeline
+    L = _native.lib()
+    H, W = 96, 1024                                                # 4 blocks
+    packed = [natural_packed12(np.random.default_rng(300 + k), H, W) for k in range(3)]
+    frames = [torch.from_numpy(packed[k % 3]).to(dev) for k in range(64)]
+    refs = [c_oracle.pipeline12_reinhard(p, work="f16", out="f16") for p in packed]
+    bp = BatchPipeline(64, H, W, dev, whole_frame=True)
+    outs = bp(frames)
+    assert bp.check() == [] and not bp.faulted()
+    for k in (0, 1, 2, 63):
+        assert_close(outs[k].cpu().numpy(), refs[k % 3], f"undisturbed frame {k}")
+    L.mi_isp_whole_frame_set_sabotage(1)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = bp(frames)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        L.mi_isp_whole_frame_set_sabotage(-1)
+    assert bp.faulted(), "the mailbox must tell without a synchronisation of the library's"
+    assert dt < 2.0, f"a launch that lost one block took {dt:.2f} s"
+    with pytest.warns(RuntimeWarning, match="timed out"):
+        lost = bp.check()
+    assert 0 in lost
+    for k in range(64):
+        assert_close(outs[k].cpu().numpy(), refs[k % 3], f"repaired frame {k}")
+    outs = bp(frames)                                              # and the next launch is undisturbed again
+    assert bp.check() == []
+    assert_close(outs[5].cpu().numpy(), refs[2], "frame after the repair")
 
 
 @pytest.mark.parametrize("out", ["f16", "u8"])
@@ -410,3 +463,11 @@ def test_camera_frame_batch_through_the_c_abi(ti, dev, rng, tonemap, resize_widt
         for k in range(n):
             assert torch.equal(outs[k], want[k]), f"group {group} camera {k}: u8 output"
             assert torch.equal(images[k], want_imgs[k]), f"group {group} camera {k}: image left behind"
+
+
+def test_isp_reuse_of_tonemapped_images_full_size(ti, dev, scenes):
+    """Two 4096 x 3072 cameras through tonemap_reinhard twice (camera_isp.py:211 then :376-403 again): the second call
+    meters the images the first one overwrote, not the subsample their load kernel left (the round-3 hole)."""
+    from tests.util import reuse_case
+    frames = [torch.from_numpy(packed_from(scenes[k], GAINS[k], OFFSETS[k])).to(dev) for k in range(2)]
+    reuse_case(ti, dev, "Camera16", frames, "reinhard_twice")

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import isp_oracle as O
-from tests.util import assert_close, assert_exact, natural_packed12, random_cfa
+from tests.util import reuse_case, assert_close, assert_exact, natural_packed12, random_cfa
 
 pytestmark = pytest.mark.gpu
 
@@ -769,6 +769,74 @@ def test_isp_metering_kernels_of_several_streams_are_put_in_order(ti, rng, dev):
             assert int(ws[off:off + 4].view(torch.int32).item()) == 0, "a metering kernel's grid barrier timed out"
 
 
+def test_isp_metering_timeout_leaves_the_state_alone(ti, dev):
+    """The one-launch update_metering with a poll budget of one round: some block cannot have seen all its peers.  The
+    call must fail as a whole - metrics exactly as they were, fault word and mailbox set, MeteringTimeout at the next call -
+    and never blend bounds folded from the records that happened to be there into the rolling state."""
+    from oracle import c_oracle
+    from taichi_image_amd import _native
+    from taichi_image_amd.camera_isp import MeteringTimeout
+    L = _native.lib()
+    H, W = 768, 1024                                                # 6 images: 12 blocks
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(500 + k), H, W, dark=0.02 * k)).to(dev) for k in range(6)]
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+    imgs = [isp.load_packed12(f) for f in frames]
+    refs = [im.cpu().numpy() for im in imgs]
+    st = c_oracle.IspState(0.3)
+    isp.update_metering(imgs)
+    m1 = st.update_metering(refs)
+    before = isp.metrics.clone()
+    assert_close(before.cpu().numpy(), m1, "metrics 1", rel=2e-5)
+    assert L.mi_isp_metering_faults(1) == 0
+    L.mi_isp_metering_set_poll_limit(1)
+    try:
+        isp.update_metering(imgs)
+        torch.cuda.synchronize()
+    finally:
+        L.mi_isp_metering_set_poll_limit(0)
+    assert torch.equal(isp.metrics, before), "a timed-out metering call changed the state"
+    assert L.mi_isp_metering_faults(0) != 0
+    ws = _native.workspace(H, W, dev)
+    off = int(L.mi_isp_workspace_error_offset(H, W))
+    assert int(ws[off:off + 4].view(torch.int32).item()) != 0
+    ws[off:off + 4].zero_()
+    with pytest.raises(MeteringTimeout):
+        isp.update_metering(imgs)
+    isp.update_metering(imgs)                                       # the mailbox was cleared by the report: back to normal
+    assert_close(isp.metrics.cpu().numpy(), st.update_metering(refs), "metrics after the failed call", rel=2e-5)
+
+
+def test_resident_grids_of_both_kinds_share_one_order(ti, dev):
+    """A one-launch metering grid and a whole-frame grid on two streams: each needs all its blocks resident, so the library
+    puts them in ONE order (round 3 kept two, and the two kinds could hold half of the chip each until their budgets ran
+    out).  Results equal those of the same work on one stream; no fault word, no mailbox."""
+    from taichi_image_amd import _native
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    L = _native.lib()
+    H, W = 768, 1024
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(600 + k), H, W, dark=0.03 * k)).to(dev) for k in range(6)]
+    big = torch.from_numpy(natural_packed12(np.random.default_rng(7), 1536, 2048)).to(dev)
+    cam = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+    imgs = [cam.load_packed12(f) for f in frames]
+    cam.update_metering(imgs)
+    want_m = cam.metrics.clone()
+    want_o = pipeline12_reinhard(big, whole_frame=True).clone()
+    torch.cuda.synchronize()
+    assert L.mi_isp_whole_frame_faults(1) == 0 and L.mi_isp_metering_faults(1) == 0
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    cams = [ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev) for _ in range(8)]
+    outs = []
+    for k in range(8):
+        with torch.cuda.stream(s1):
+            cams[k].update_metering(imgs)
+        with torch.cuda.stream(s2):
+            outs.append(pipeline12_reinhard(big, whole_frame=True))
+    torch.cuda.synchronize()
+    assert L.mi_isp_whole_frame_faults(1) == 0 and L.mi_isp_metering_faults(1) == 0
+    for k in range(8):
+        assert torch.equal(cams[k].metrics, want_m) and torch.equal(outs[k], want_o), k
+
+
 @pytest.mark.parametrize("cam", ["Camera16", "Camera32"])
 def test_isp_tonemap_reinhard_yuv420_fused(ti, rng, dev, cam):
     """The fused second pass + YUV 4:2:0 conversion equals converting the u8 outputs of tonemap_reinhard, bit
@@ -864,3 +932,97 @@ def test_load_packed_batch_equals_single_loads(ti, rng, dev, cam, shape, rw, n):
     ub = b.tonemap_reinhard([b.load_packed12(f) for f in frames], gamma=0.7)
     assert torch.equal(a.metrics, b.metrics) and all(torch.equal(x, y) for x, y in zip(ua, ub))
     assert isp.load_packed12_batch([]) == []
+
+
+# ---- re-use of images the library has tone-mapped in place (camera_isp.py:211 then :376-403 again) -----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam", ["Camera16", "Camera32"])
+@pytest.mark.parametrize("sequence", ["reinhard_twice", "reinhard_then_linear", "kernel_then_metering"])
+def test_isp_reuse_of_tonemapped_images(ti, dev, cam, sequence):
+    """(200, 512): the load kernel leaves the metering subsample (W % 8 == 0, no resize) - the case that went stale."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/liborc_isp.so not built")
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(70 + k), 200, 512, dark=0.05 * k)).to(dev) for k in range(3)]
+    reuse_case(ti, dev, cam, frames, sequence)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["inference_mode", "no_grad"])
+@pytest.mark.parametrize("cam", ["Camera16", "Camera32"])
+def test_isp_under_inference_mode_and_no_grad(ti, dev, cam, mode):
+    """The reference's bench runs inside torch.inference_mode() (bench/camera_isp.py:53): tensors created there have no
+    version counter.  load_packed12 (single and batched) -> tonemap_reinhard twice must work and agree with the oracle."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/liborc_isp.so not built")
+    packed = [natural_packed12(np.random.default_rng(90 + k), 200, 512, dark=0.04 * k) for k in range(2)]
+    with getattr(torch, mode)():
+        frames = [torch.from_numpy(p).to(dev) for p in packed]
+        isp = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.5, device=dev)
+        st = c_oracle.IspState(0.5)
+        imgs = isp.load_packed12_batch(frames[:1]) + [isp.load_packed12(frames[1])]
+        if mode == "inference_mode":
+            assert all(torch.is_inference(im) and not hasattr(im, "_mi_metering_sub") for im in imgs)
+        for step in range(2):
+            cur = [im.cpu().numpy() for im in imgs]
+            outs = isp.tonemap_reinhard(imgs, gamma=0.6)
+            m = st.update_metering(cur)
+            assert_close(isp.metrics.cpu().numpy(), m, f"metrics {step}", rel=2e-5)
+            for k in range(2):
+                ref_u8, ref_after = c_oracle.reinhard_isp(cur[k], m, gamma=0.6)
+                assert_close(outs[k].cpu().numpy(), ref_u8, f"u8 step {step} img {k}")
+                assert_close(imgs[k].cpu().numpy(), ref_after, f"p step {step} img {k}")
+
+
+@pytest.mark.gpu
+def test_in_place_write_is_visible_to_torch(ti, dev):
+    """What the library writes through raw pointers moves the tensor's version counter (views included)."""
+    frame = torch.from_numpy(natural_packed12(np.random.default_rng(5), 64, 256)).to(dev)
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=1.0, device=dev)
+    im = isp.load_packed12(frame)
+    view = im[:8]
+    v0 = im._version
+    isp.tonemap_reinhard([im])
+    assert im._version > v0 and view._version == im._version
+
+
+# ---- the HIP path against the COMMITTED fixtures (tests/golden/golden_small.npz) -----------------------------------
+@pytest.mark.gpu
+def test_hip_path_against_the_committed_fixtures(ti, dev):
+    """Every vector of golden_small.npz (tests/golden/make_golden.py) recomputed by the HIP kernels and compared with the
+    file itself - not with the live oracle: an edit that moved oracle and kernel together would still fail here."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_small.npz"))
+    enc = g["dec_in"]
+    assert_exact(ti.packed.decode12(enc, dtype=ti.types.u16), g["dec_std_u16"], "dec_std_u16")
+    assert_exact(ti.packed.decode12(enc, dtype=ti.types.u16, ids_format=True), g["dec_ids_u16"], "dec_ids_u16")
+    assert_exact(ti.packed.decode12(enc, dtype=ti.types.f16, scaled=True), g["dec_std_f16s"], "dec_std_f16s")
+    assert_exact(ti.packed.decode12(enc, dtype=ti.types.f32, scaled=True, ids_format=True), g["dec_ids_f32s"], "dec_ids_f32s")
+    assert_exact(ti.packed.decode16(enc, dtype=ti.types.f16, scaled=True), g["dec16_f16s"], "dec16_f16s")
+    for p in range(4):
+        assert_exact(ti.bayer.bayer_to_rgb(g["cfa_u16"], pat(ti, p)), g[f"rgb_u16_p{p}"], f"rgb_u16_p{p}")
+        assert_exact(ti.bayer.bayer_to_rgb(g["cfa_f16"], pat(ti, p)), g[f"rgb_f16_p{p}"], f"rgb_f16_p{p}")
+    ccm = O.isp_color_matrix(True, O.DEFAULT_WB, O.DEFAULT_CC)          # (plain numpy arithmetic of camera_isp.py:360-369)
+    assert_exact(ti.bayer.bayer_to_rgb(g["cfa_f16"], pat(ti, 0), correct_colors=ccm), g["rgb_f16_ccm"], "rgb_f16_ccm")
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    for p, ids in ((0, False), (2, True)):
+        tag = f"p{p}{'i' if ids else 's'}"
+        raw = torch.from_numpy(g[f"packed_{tag}"]).to(dev)
+        for wf in ((False, True) if not ids else (False,)):              # the multi-pass chain and the whole-frame kernel
+            got = pipeline12_reinhard(raw, pat(ti, p), ids, whole_frame=wf).cpu().numpy()
+            assert_close(got, g[f"pipe_f16_{tag}"], f"pipe_f16_{tag} whole_frame={wf}")
+            got8 = pipeline12_reinhard(raw, pat(ti, p), ids, dtype=ti.types.u8, gamma=0.6, whole_frame=wf).cpu().numpy()
+            assert_close(got8, g[f"pipe_u8_{tag}"], f"pipe_u8_{tag} whole_frame={wf}")
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, resize_width=40, device=dev)
+    im = isp.load_packed12(torch.from_numpy(g["packed_p0s"]).to(dev))
+    assert_exact(im.cpu().numpy(), g["isp_img_f16"], "isp_img_f16")
+    isp.update_metering([im, im])
+    assert_close(isp.metrics.cpu().numpy(), g["isp_metrics_1"], "isp_metrics_1", rel=2e-5)
+    lin = isp.tonemap_linear([im], gamma=0.8)[0]
+    assert_close(isp.metrics.cpu().numpy(), g["isp_metrics_2"], "isp_metrics_2", rel=2e-5)
+    assert_close(lin.cpu().numpy(), g["isp_linear_u8"], "isp_linear_u8")
+    out = isp.tonemap_only(im, isp.metrics, 0.6, 1.0, 1.0, 0.0)
+    assert_close(out.cpu().numpy(), g["isp_u8"], "isp_u8")
+    assert_close(im.cpu().numpy(), g["isp_after"], "isp_after")
+    assert_exact(ti.interpolate.resize_bilinear(g["scene_f32"], (30, 20), 0.46875), g["resize_f32"], "resize_f32")
