@@ -537,7 +537,8 @@ extern "C" int mi_isp_workspace_check(void* ws_dev, int n_frames, int H, int W, 
       // then never carry the tag of a later launch (a graph replay repeats the host's part of the tag)
       float* partials = reinterpret_cast<float*>(static_cast<char*>(ws_dev) + (size_t)i * ws_bytes) + FP_COUNT;
       const size_t stride = (size_t)mi_partial_cap(H, W);
-      MI_HIP(hipMemset(partials + (size_t)mega::MROW_BAR0 * stride, 0, (size_t)24 * stride * sizeof(float)));
+      MI_HIP(hipMemset(partials + (size_t)mega::MROW_BAR0 * stride, 0,
+                       (size_t)(mega::MROW_END - mega::MROW_BAR0) * stride * sizeof(float)));
     }
   }
   *n_failed = bad;

@@ -110,7 +110,10 @@ constexpr int ROW_U4 = 64 * 3;       // one f16 row of a wave: 64 lanes x 3 x 16
 #endif
 constexpr int REC = MI_MEGA_REC;
 constexpr int MROW_BAR0 = strm::MEGA_ROW_BASE, MROW_BAR1 = MROW_BAR0 + 8, MROW_BAR2 = MROW_BAR1 + 8;
-static_assert(MROW_BAR2 + 8 <= strm::PART_ROWS, "the whole-frame kernel's rows must fit the workspace");
+// Two-level barriers (round 4): behind the three record areas one partial row per barrier for the RESULTS - the scalars
+// an XCD's leader derived, one 256-byte slot per XCD - and one row of claim words (64 bytes apart: barrier * 8 + XCD).
+constexpr int MROW_RES = MROW_BAR2 + 8, MROW_CLAIM = MROW_RES + 3, MROW_END = MROW_CLAIM + 1;
+static_assert(MROW_END <= strm::PART_ROWS, "the whole-frame kernel's rows must fit the workspace");
 static_assert(REC >= 64 && REC % 16 == 0, "three 16-byte chunks and the beacon per record");
 constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
 
@@ -206,6 +209,27 @@ MI_DEV float wsum(float v) {
 #ifndef MI_MEGA_ASM_REDUCE
 #define MI_MEGA_ASM_REDUCE 1
 #endif
+#if defined(MI_MEGA_DENSE) && MI_MEGA_DENSE && defined(MI_MEGA_TWO_LEVEL) && !MI_MEGA_TWO_LEVEL
+#error "dense records are for the two-level barrier (no watch stage, 32 pollers)"
+#endif
+#ifndef MI_MEGA_TWO_LEVEL             /* one block per XCD folds the records, the others take its result from the L2: measured, no gain (barrier_fold) */
+#define MI_MEGA_TWO_LEVEL 0
+#endif
+#ifndef MI_MEGA_LEADER_WATCH          /* the leaders keep round 3's watch stage (measurement) */
+#define MI_MEGA_LEADER_WATCH 0
+#endif
+#ifndef MI_MEGA_RESULT_AUX            /* cache policy of the result record's store: 0 = plain, the line stays in the XCD's L2 (an sc1 store drops it) */
+#define MI_MEGA_RESULT_AUX 0
+#endif
+#ifndef MI_MEGA_FOLLOW_AUX            /* ... and of the followers' loads of it: 16 = sc1, past the L1, served by the L2 */
+#define MI_MEGA_FOLLOW_AUX 16
+#endif
+#ifndef MI_MEGA_DENSE                 /* records 16 bytes apart (chunk c of block b at c * 8192 + 16 b) instead of one per 256-byte block: only 32 leader waves poll them */
+#define MI_MEGA_DENSE 0
+#endif
+#ifndef MI_MEGA_FOLLOW_SLEEP          /* units of 64 cycles between two looks of a follower at its XCD's result */
+#define MI_MEGA_FOLLOW_SLEEP 2
+#endif
 #if MI_MEGA_ASM_REDUCE
 #define MI_WMIN wmin
 #define MI_WMAX wmax
@@ -251,8 +275,12 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(area, 0, (int)((size_t)8 * stride * sizeof(float)), 0x00020000);
     if (lane < NCH) mine.w = tag ^ rec_hash(mine.x, mine.y, mine.z);
+#if MI_MEGA_DENSE
+    const uint32_t off = withhold || lane >= NCH ? INVALID_OFF : (uint32_t)lane * 8192u + (uint32_t)block * 16u;
+#else
     const uint32_t off = withhold ? INVALID_OFF
                                   : (lane < NCH ? (uint32_t)block * REC + 16u * lane : (lane == NCH ? (uint32_t)block * REC + 48u : INVALID_OFF));
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(mine, rs, off, 0, MI_MEGA_POST_AUX);   // aux 16 = sc1: write-through, visible to the other XCDs
   }
 }
@@ -264,6 +292,7 @@ struct FoldLds {
   float mm[WAVES][4];
   float sum[WAVES][5];
   float keep[7];                          // barrier 0's totals of the speculative statistics, for barrier 1 (bounds other than (0, 1))
+  unsigned lead[4];                       // per barrier: 2 * frames passed + (this block leads its XCD at the current one)
   unsigned faulted;                       // latched by the first wave of the block whose poll budget runs out (barrier_fold: budget)
 };
 
@@ -286,6 +315,104 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   unsigned role = 0;
   if (lane == 0) role = __hip_atomic_fetch_add(fl.ticket + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   role = __builtin_amdgcn_readfirstlane(role) & (WAVES - 1);
+#if MI_MEGA_TWO_LEVEL
+  // ---- two levels: ONE block per XCD folds the chip's records (from memory), the other 63 take its result from the L2 ----
+  // What the finalize leaves for the next phase travels as a result record: RC chunks {3 floats, tag ^ rec_hash} in the
+  // XCD's slot.  The leader is the XCD's first block to ask (an exchange on the XCD's claim word, executed in ITS L2 - every
+  // block that touches the word shares that L2); it polls and folds exactly as every block did in round 3, so the scalars
+  // are the same bits in every XCD.  A follower polls the slot through the L2 (sc1 loads, past its CU's L1; the leader's
+  // plain store leaves the line in that very L2).  512 x fewer polls of memory: the leaders need no watch stage, and
+  // nobody's polling slows a block that is still in its phase.
+  constexpr int R_BASE = NV == 9 ? FP_LO : (NV == 1 ? FP_BMIN : FP_LO2);          // sh_fp[R_BASE, R_BASE + R_NF) ...
+  constexpr int R_NF = NV == 9 ? 15 : (NV == 1 ? 12 : 3), R_KEEP = NV == 9 ? 7 : 0; // ... then fl.keep[0, R_KEEP)
+  constexpr int RC = (R_NF + R_KEEP + 2) / 3;
+  static_assert(RC * 16 <= 256, "a result fits its slot");
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));                  // XCC_ID[3:0]: where this CU lives
+  float* const partials_ = ws + FP_COUNT;
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      partials_ + (size_t)(MROW_RES + (NV == 9 ? 0 : (NV == 1 ? 1 : 2))) * a.t.part_stride, 0, 8 * 256, 0x00020000);
+  auto publish_result = [&]() {                         // the whole wave; sh_fp / fl.keep were written by its lane 0
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    float f3[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int j = 3 * lane + e;
+      f3[e] = j < R_NF ? sh_fp[R_BASE + (j < R_NF ? j : 0)] : (j < R_NF + R_KEEP ? fl.keep[j < R_NF + R_KEEP ? j - R_NF : 0] : 0.f);
+    }
+    u4 mine = {__builtin_bit_cast(uint32_t, f3[0]), __builtin_bit_cast(uint32_t, f3[1]), __builtin_bit_cast(uint32_t, f3[2]), 0u};
+    mine.w = tag ^ rec_hash(mine.x, mine.y, mine.z);
+    __builtin_amdgcn_raw_buffer_store_b128(mine, rrs, lane < RC ? xcc * 256u + 16u * lane : INVALID_OFF, 0, MI_MEGA_RESULT_AUX);
+  };
+  unsigned lead = 0;
+  if (role == 0) {
+    unsigned old = tag;
+    if (lane == 0) {
+      unsigned* claim = reinterpret_cast<unsigned*>(partials_ + (size_t)MROW_CLAIM * a.t.part_stride) + ((unsigned)bar * 8u + xcc) * 16u;
+      old = __hip_atomic_exchange(claim, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    lead = __builtin_amdgcn_readfirstlane(old) != tag ? 1u : 0u;
+    if (lane == 0) __hip_atomic_store(fl.lead + bar, 2u * seq + lead, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    unsigned naps = 0, w = 0;
+    while ((int)(((w = __hip_atomic_load(fl.lead + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 1) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(MI_MEGA_FLAG_SLEEP);
+      if (++naps > 64u * m.spin_limit) break;
+    }
+    lead = __builtin_amdgcn_readfirstlane(w) & 1u;
+  }
+  if (!lead) {
+    if (role == 0) {
+      const unsigned budget_f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.faulted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                                    ? 1u : m.spin_limit;
+      const uint32_t off = lane < RC ? xcc * 256u + 16u * lane : INVALID_OFF;
+      uint32_t rx = 0u, ry = 0u, rz = 0u;
+      unsigned spins_f = 0;
+      for (;;) {
+        // (sc1 loads: they bypass this CU's L1 - which no other CU's store ever refreshes: an sc0 load is served by it like a
+        // plain one and never saw the result - and are served by the XCD's L2, where the leader's plain store has left the line)
+        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, MI_MEGA_FOLLOW_AUX);
+        rx = t.x; ry = t.y; rz = t.z;
+        const bool ok = lane >= RC || (t.w ^ rec_hash(t.x, t.y, t.z)) == tag;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        if (++spins_f >= budget_f) {
+          if (lane == 0) {
+            __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m.mailbox) __hip_atomic_store(m.mailbox, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&fl.faulted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(MI_MEGA_FOLLOW_SLEEP);
+      }
+      if (stamps && lane == 0) stamps[0] = MI_STAMP_NOW();
+      if (lane < RC) {
+        const uint32_t w3[3] = {rx, ry, rz};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const int j = 3 * lane + e;
+          const float x = __builtin_bit_cast(float, w3[e]);
+          if (j < R_NF) sh_fp[R_BASE + j] = x;
+          else if (j < R_NF + R_KEEP) fl.keep[j - R_NF] = x;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (blockIdx.x == 0 && lane < RC) {                 // block 0 leaves the frame's scalars in FrameParams
+#pragma unroll
+        for (int e = 0; e < 3; ++e) if (3 * lane + e < R_NF) ws[R_BASE + 3 * lane + e] = sh_fp[R_BASE + 3 * lane + e];
+      }
+      if (stamps && lane == 0) stamps[2] = MI_STAMP_NOW();
+      if (lane == 0) __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      unsigned naps = 0;
+      while ((int)(__hip_atomic_load(fl.flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(MI_MEGA_FLAG_SLEEP);
+        if (++naps > 64u * m.spin_limit) break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
+#endif
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(area), 0, (int)((size_t)8 * a.t.part_stride * sizeof(float)), 0x00020000);
   u4 v[2][NCH];
@@ -317,7 +444,11 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
+#if MI_MEGA_DENSE
+        const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)c * 8192u + (uint32_t)((int)role * 128 + u * 64 + lane) * 16u;
+#else
         const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)((int)role * 128 + u * 64 + lane) * REC + 16u * c;
+#endif
         const u4 t = __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, AUX);
         v[u][c] = have[u][c] ? v[u][c] : t;
       }
@@ -347,7 +478,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   // Whichever blocks post last are deliberately NOT waited for here: stage 1 asks for whatever is still missing every
   // round, so a straggler's record is seen one round trip after it lands.
   bool waited = false;                                // (wave-uniform)
-  if (budget > 1) {                             // (a budget of 1 - the fault test - polls at once)
+  if (budget > 1 && !(MI_MEGA_TWO_LEVEL && !MI_MEGA_LEADER_WATCH)) {   // (a budget of 1 - the fault test - polls at once; 32 leader waves need no watch)
     const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
     const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + BEACON_OFF : INVALID_OFF;
     const bool idle = !(lane < 2 && watch >= 0);
@@ -490,12 +621,18 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
         ew::finalize_scalars_fast(FIN, fa, tot);
       }
       if (stamps) stamps[2] = MI_STAMP_NOW();
+#if !MI_MEGA_TWO_LEVEL
       __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
       // block 0 leaves the frame's scalars in FrameParams, as the multi-pass chain does (callers may read them back)
       if (blockIdx.x == 0) {
         for (int i = 0; i <= FP_MAXOUT; ++i) ws[i] = sh_fp[i];
       }
     }
+#if MI_MEGA_TWO_LEVEL
+    publish_result();                                  // first the XCD's 63 other blocks, then this block's own waves
+    if (lane == 0) __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
   } else {
     unsigned naps = 0;
     while ((int)(__hip_atomic_load(fl.flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) {
@@ -619,6 +756,20 @@ MI_DEV float pk_hi(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return
 #ifndef MI_MEGA_PRE2
 #define MI_MEGA_PRE2 1
 #endif
+// rgb_gray of the resident pixels computed while the wave waits at barrier 0 (frames with bounds (0, 1), color_adapt == 0)
+#ifndef MI_MEGA_GRAY_PRE                /* measured: only two rows' worth fits the registers, and those buy nothing (44.46 against 44.36 us) */
+#define MI_MEGA_GRAY_PRE 0
+#endif
+#ifndef MI_MEGA_TONE_NP                 /* pixels of a row whose Reinhard chains run in lockstep (tone_row); 1 = the compiler's order.  Measured, unit /
+                                           non-unit frames: 1: 44.30 / 51.66, 2: 44.44 / 52.40, 4: 44.19 / 51.99 us - nothing (see tone_row) */
+#define MI_MEGA_TONE_NP 1
+#endif
+#ifndef MI_MEGA_GRAY_LO                /* the resident rows [LO, HI) whose gray is computed ahead: the registers decide */
+#define MI_MEGA_GRAY_LO 0
+#endif
+#ifndef MI_MEGA_GRAY_HI
+#define MI_MEGA_GRAY_HI 2
+#endif
 
 // RGB: color_adapt != 0 (per-channel sums in the statistics).  Two kernels instead of a run-time flag: with both kinds of
 // statistics in one body the register allocator spilled 13 VGPRs to scratch in phase A and reloaded them in B / C / D,
@@ -640,7 +791,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   __shared__ float sh_fp[FP_COUNT];
   __shared__ unsigned arrived;
   __shared__ FoldLds fl;
-  if (threadIdx.x < 4) { fl.ticket[threadIdx.x] = 0; fl.done[threadIdx.x] = 0; fl.flag[threadIdx.x] = 0; }
+  if (threadIdx.x < 4) { fl.ticket[threadIdx.x] = 0; fl.done[threadIdx.x] = 0; fl.flag[threadIdx.x] = 0; fl.lead[threadIdx.x] = 0; }
   if (threadIdx.x == 0) { arrived = 0; fl.faulted = 0; }
   if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = 0.f;
 
@@ -888,6 +1039,28 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     unpack_row(pk, t);
   };
 
+  // Between the post and the first poll of barrier 0 (the median wave waits ~5 us there, the last one ~2.5): rgb_gray of
+  // every resident pixel, for phase C - which is bound by VALU issue - under the assumption that the bounds will turn out
+  // to be (0, 1) (the normalisation of tonemap.py:13 is then the identity and the gray of reinhard_func, tonemap.py:120, is
+  // that of the stored pixel).  96 registers that nobody else wants while the wave waits; frames with other bounds
+  // ignore them.  Straight from the packed halves (gray_pk: three v_fma_mix_f32, fma roundings); phase D's second
+  // evaluation of the LDS rows derives it the same way, so the bounds phase C finds are those of the values phase D emits.
+#if MI_MEGA_GRAY_PRE
+  constexpr int GLO = MI_MEGA_GRAY_LO, GHI = MI_MEGA_GRAY_HI;
+  float gpre[GHI - GLO][8];
+  {
+    const float pw0 = vgpr(0.299f), pw1 = vgpr(0.587f), pw2 = vgpr(0.114f);
+    static_for<GLO, GHI>([&](auto rrc) {
+      constexpr int RR = decltype(rrc)::value;
+      fresh(gpre[RR - GLO]);
+      if (r_begin + RR < r_end) {
+        uint32_t pk[12];
+        resident_pk(rrc, pk);
+        static_for<0, 8>([&](auto kc) { constexpr int K = decltype(kc)::value; gpre[RR - GLO][K] = gray_pk<K>(pk, pw0, pw1, pw2); });
+      }
+    });
+  }
+#endif
   // ================================ barrier 0: bounds (tonemap.py:146) ================================
   MI_MSTAMP(2);
 #ifdef MI_STREAM_STAMPS
@@ -966,17 +1139,109 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   // identity; CA0: color_adapt == 0, one pow per pixel.  The variant is chosen ONCE per phase, outside the row loops: the
   // executed code of a phase is then one contiguous stretch (the instruction cache is shared by two CUs and a wave's
   // straight-line code is ~100 KB; interleaved dead variants cost misses).
-  auto tone_row = [&](auto unit_c, auto ca0_c, const float (&t)[24], float (&q)[24]) {
+  // g8: rgb_gray of the row's pixels when it is known already (UNIT && CA0 only: the pixel IS the normalised pixel)
+  auto adapt_g = [&](float g) __attribute__((always_inline)) {     // reinhard_adapt_ca0 from the gray (tonemap.py:121-129)
+    const float am = rk.mean3[0] + rk.la * (g - rk.mean3[0]);
+    return hw_pow(rk.ei * am, rk.map_key);
+  };
+  // color_adapt == 0: NP pixels of a row in LOCKSTEP, one dependent step of each per stage, the stages pinned by
+  // scheduling barriers.  Left to itself the compiler - short of registers here - emits one pixel after the other, each a
+  // chain of ~15 dependent instructions (mul fmac fmac sub fma mul log [s_nop] mul exp [s_nop] add rcp [s_nop] mul: the
+  // round-3 census of phase C): a dependent VALU instruction issues 7.4 cycles after its producer, so a wave got an issue
+  // slot every ~7 cycles where two waves of independent work get one every 2.3 each, and every transcendental's consumer
+  // waited out its hazard in an s_nop.  With NP chains side by side the next instruction of a wave is never the consumer of
+  // the previous one (census: the 146 s_nop of phase C are gone).  MEASURED: no gain (MI_MEGA_TONE_NP) - with two waves per
+  // SIMD the other wave already filled the slots a chain leaves open; phase C's ~10 us are its instruction count (440
+  // transcendentals at 7.4 cycles, ~610 single-rate and ~1260 double-rate instructions per wave), not its order.  Off.
+  // The arithmetic, its order and its roundings are those of reinhard_adapt_ca0 / reinhard_map
+  // (isp_math.h: gray = fma(b, .114, fma(r, .299, g * .587)), am = fma(la, gray - mean, mean), ad = exp2(map_key *
+  // log2(ei * am)), q = x * rcp(ad + x)).
+#define MI_SB() __builtin_amdgcn_sched_barrier(0)
+  auto adapt_np = [&](auto np_c, const float (*x)[3], float* ad) __attribute__((always_inline)) {
+    constexpr int NP = decltype(np_c)::value;
+    float g[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = x[p][1] * 0.587f;
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = __builtin_fmaf(x[p][0], 0.299f, g[p]);
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = __builtin_fmaf(x[p][2], 0.114f, g[p]);
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = g[p] - rk.mean3[0];
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = __builtin_fmaf(rk.la, g[p], rk.mean3[0]);
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = rk.ei * g[p];
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = hw_log2(g[p]);
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) g[p] = rk.map_key * g[p];
+    MI_SB();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) ad[p] = hw_exp2(g[p]);
+    MI_SB();
+  };
+  auto tone_row = [&](auto unit_c, auto ca0_c, const float (&t)[24], float (&q)[24], const float* g8 = nullptr) {
     constexpr bool UNIT = decltype(unit_c)::value, CA0 = decltype(ca0_c)::value;
+    if constexpr (CA0 && MI_MEGA_TONE_NP > 1 && !MI_MEGA_GRAY_PRE) {
+      constexpr int NP = MI_MEGA_TONE_NP;
+      static_for<0, 8 / NP>([&](auto gc) {
+        constexpr int P0 = decltype(gc)::value * NP;
+        float x[NP][3], ad[NP], r[NP][3];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) x[p][ch] = UNIT ? t[3 * (P0 + p) + ch] : norm_fma(t[3 * (P0 + p) + ch]);
+        MI_SB();
+        adapt_np(std::integral_constant<int, NP>{}, x, ad);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) r[p][ch] = ad[p] + x[p][ch];
+        MI_SB();
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) r[p][ch] = hw_rcp(r[p][ch]);
+        MI_SB();
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) q[3 * (P0 + p) + ch] = x[p][ch] * r[p][ch];
+        MI_SB();
+      });
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float x[3], o[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm_fma(t[3 * k + ch]);
-      reinhard_px<CA0>(x, rk, o);
+      if constexpr (UNIT && CA0 && MI_MEGA_GRAY_PRE) {
+        const float ad = adapt_g(g8[k]);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[ch] = reinhard_map(x[ch], ad);
+      } else {
+        reinhard_px<CA0>(x, rk, o);
+      }
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) q[3 * k + ch] = o[ch];
     }
+  };
+  // a resident row as fp32 values and (unit bounds, color_adapt == 0) its gray, from the packed halves
+  auto resident_g = [&](auto rrc, float (&t)[24], float (&g8)[8]) {
+    uint32_t pk[12];
+    resident_pk(rrc, pk);
+    const float pw0 = vgpr(0.299f), pw1 = vgpr(0.587f), pw2 = vgpr(0.114f);
+    static_for<0, 8>([&](auto kc) { constexpr int K = decltype(kc)::value; g8[K] = gray_pk<K>(pk, pw0, pw1, pw2); });
+    unpack_row(pk, t);
   };
   auto dispatch = [&](auto&& phase) {
     if (ca0) {
@@ -998,14 +1263,44 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   // mapped value are those of its smallest and largest channel: two reciprocals per pixel instead of three (the value
   // is the same instruction sequence on the same operand; where the hardware reciprocal is not monotone to the last
   // bit the bound can differ from the three-channel one by an ulp - the scalars' contract is 1e-4).
-  auto tone_bounds_row = [&](auto unit_c, const float (&t)[24]) {
+  auto tone_bounds_row = [&](auto unit_c, const float (&t)[24], const float* g8 = nullptr) {
     constexpr bool UNIT = decltype(unit_c)::value;
+    if constexpr (MI_MEGA_TONE_NP > 1 && !MI_MEGA_GRAY_PRE) {
+      constexpr int NP = MI_MEGA_TONE_NP;
+      static_for<0, 8 / NP>([&](auto gc) {
+        constexpr int P0 = decltype(gc)::value * NP;
+        float x[NP][3], ad[NP], lo_[NP], hi_[NP], rl[NP], rh[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) x[p][ch] = UNIT ? t[3 * (P0 + p) + ch] : norm_fma(t[3 * (P0 + p) + ch]);
+        MI_SB();
+        adapt_np(std::integral_constant<int, NP>{}, x, ad);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { lo_[p] = fminf(x[p][0], fminf(x[p][1], x[p][2])); hi_[p] = fmaxf(x[p][0], fmaxf(x[p][1], x[p][2])); }
+        MI_SB();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { rl[p] = ad[p] + lo_[p]; rh[p] = ad[p] + hi_[p]; }
+        MI_SB();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { rl[p] = hw_rcp(rl[p]); rh[p] = hw_rcp(rh[p]); }
+        MI_SB();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { rl[p] = lo_[p] * rl[p]; rh[p] = hi_[p] * rh[p]; }
+        MI_SB();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { vmin = fminf(vmin, rl[p]); vmax = fmaxf(vmax, rh[p]); }
+      });
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float x[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm_fma(t[3 * k + ch]);
-      const float ad = reinhard_adapt_ca0(x, rk);       // (the very function phase D evaluates again)
+      float ad;                                         // (the very function phase D evaluates again)
+      if constexpr (UNIT && MI_MEGA_GRAY_PRE) ad = adapt_g(g8[k]);
+      else ad = reinhard_adapt_ca0(x, rk);
       const float xmin = fminf(x[0], fminf(x[1], x[2])), xmax = fmaxf(x[0], fmaxf(x[1], x[2]));
       vmin = fminf(vmin, reinhard_map(xmin, ad));
       vmax = fmaxf(vmax, reinhard_map(xmax, ad));
@@ -1018,12 +1313,24 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     if (r_begin + RR < r_end) {
       float t[24];
       resident(rrc, t);
+#if MI_MEGA_GRAY_PRE
+      // (rows outside [GLO, GHI): the gray from the unpacked pixel, mul / fma / fma as gray_pk rounds it)
+      float g8_[8];
+      const float* g8 = g8_;
+      if constexpr (RR >= GLO && RR < GHI) g8 = gpre[RR - GLO];
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g8_[k] = __builtin_fmaf(t[3 * k + 2], 0.114f, __builtin_fmaf(t[3 * k + 1], 0.587f, t[3 * k] * 0.299f));
+      }
+#else
+      const float* g8 = nullptr;
+#endif
       if (RR < NL && ca0) {                            // (wave-uniform)
-        if (unit) tone_bounds_row(std::true_type{}, t);
+        if (unit) tone_bounds_row(std::true_type{}, t, g8);
         else tone_bounds_row(std::false_type{}, t);
       } else {
         float q[24];
-        dispatch([&](auto unit_c, auto ca0_c) { tone_row(unit_c, ca0_c, t, q); });
+        dispatch([&](auto unit_c, auto ca0_c) { tone_row(unit_c, ca0_c, t, q, g8); });
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           vmin = fminf(vmin, fminf(q[3 * k], fminf(q[3 * k + 1], q[3 * k + 2])));
@@ -1063,9 +1370,10 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     static_for<0, PRE2>([&](auto rrc) {
       constexpr int RR = decltype(rrc)::value;
       if (r_begin + RR < r_end) {
-        float t[24];
-        resident(rrc, t);
-        tone_row(unit_c, ca0_c, t, qpre[RR]);
+        float t[24], g8[8];
+        if constexpr (decltype(unit_c)::value && decltype(ca0_c)::value && MI_MEGA_GRAY_PRE) resident_g(rrc, t, g8);
+        else resident(rrc, t);
+        tone_row(unit_c, ca0_c, t, qpre[RR], g8);
       }
     });
   });
@@ -1151,9 +1459,10 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       static_for<PRE2, NL>([&](auto rrc) {
         constexpr int RR = decltype(rrc)::value;
         if (r_begin + RR < r_end) {
-          float t[24], q[24];
-          resident(rrc, t);
-          tone_row(unit_c, ca0_c, t, q);
+          float t[24], q[24], g8[8];
+          if constexpr (decltype(unit_c)::value && decltype(ca0_c)::value && MI_MEGA_GRAY_PRE) resident_g(rrc, t, g8);
+          else resident(rrc, t);
+          tone_row(unit_c, ca0_c, t, q, g8);
           finish_row(rrc, q);
         }
 #ifndef MI_MEGA_NOPREFETCH
