@@ -84,6 +84,8 @@ SIGNATURES = {
     "mi_isp_whole_frame_set_sabotage": (c_int, [c_int]),
     "mi_isp_metering_faults": (c_int, [c_int]),
     "mi_isp_metering_set_poll_limit": (c_int, [ctypes.c_uint]),
+    "mi_isp_reinhard_faults": (c_int, [c_int]),
+    "mi_isp_reinhard_set_poll_limit": (c_int, [ctypes.c_uint]),
     "mi_isp_workspace_error_offset": (ctypes.c_size_t, [c_int, c_int]),
     "mi_isp_profile_enable": (c_int, [c_int, c_int]),
     "mi_isp_profile_collect": (c_int, [POINTER(c_float), POINTER(c_int)]),   # float[4]

@@ -44,6 +44,11 @@ class MeteringTimeout(RuntimeError):
     update_metering / tonemap call (one host read of the device's mailbox, no synchronisation)."""
 
 
+class TonemapTimeout(RuntimeError):
+    """The grid-wide wait of an earlier one-launch tonemap_reinhard on this device (max_out, camera_isp.py:213) timed out:
+    the u8 outputs of that call are invalid.  Raised by the next metering / tonemap call (a host read of the mailbox)."""
+
+
 def _version_of(t):
     """torch's write counter of a tensor, None where there is none (inference tensors do not track one)."""
     try:
@@ -381,6 +386,9 @@ def camera_isp(name: str, dtype=types.f32):
                 if L.mi_isp_metering_faults(1):
                     raise MeteringTimeout("an earlier update_metering on this device timed out at its grid barrier: its "
                                           "metrics were left unchanged and outputs tone-mapped with them are invalid")
+                if L.mi_isp_reinhard_faults(1):
+                    raise TonemapTimeout("an earlier tonemap_reinhard on this device timed out waiting for an image's "
+                                         "max_out: the outputs of that call are invalid")
             if self.process_group is None:
                 metering = prev.clone()
                 _native.check(L.mi_isp_metering(ptrs, len(images), H, W, stride, dtype.code,

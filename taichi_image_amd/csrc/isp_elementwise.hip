@@ -833,6 +833,206 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
 }
 
 // ---------------------------------------------------------------------------------------------
+// ISP Reinhard (camera_isp.py:177-218) of a whole camera group in ONE persistent launch (round 4).
+//
+// The two passes of rgb_pass_kernel<PM_ISP_RH_P1 / P2> communicate through memory: pass 1 writes p back over the image
+// (camera_isp.py:211 - the reference mutates its input, so that write stays), pass 2 reads it again for the final map,
+// and a kernel boundary sits between them because max_out (camera_isp.py:213) is a reduction over the whole image.
+// Here a resident grid (ISPF_BPC blocks per CU, checked against the occupancy query) keeps every image's ROUNDED p - the
+// very bytes it stores - in registers: 12 packed dwords per 8-pixel group (f16), `iters` groups per thread.  HBM sees the
+// image in, p out (the in-place semantics) and the u8 result out; the 2 B/value re-read of p and one launch are gone.
+//   P1(k)  Reinhard of image k: p stored in place and kept; the block's maximum goes to the image's max word of the
+//          block's XCD (atomic max on the bits of a non-negative float), then the XCD's arrival counter is bumped
+//   W(k)   wave 0 polls the image's 8 {count, max} pairs (one 8-byte sc1 load per lane) until the counts add up to the grid
+//   P2(k)  (p / max_out)^(1/gamma) * 255 -> u8 from the kept p (camera_isp.py:215-218)
+// PIPE: P1(k + 1) runs between P1(k)'s post and W(k), so the barrier's latency (~2-3 us after the last arrival) hides
+// behind a whole pass of the next image; two images' p are resident.  Images too large for that (up to 6 groups per
+// thread, 6.3 MP) run P1 / W / P2 one image at a time; larger ones (a 4096 x 3072 frame is 12 groups per thread: its kept p
+// does not fit the registers next to the working set) stay with the two passes.
+// The {count, max} words live in a buffer of the library's own (per device, zero at allocation), in two halves: launch n
+// uses half n & 1 and clears the other one for launch n + 1 (launches of resident-grid kernels are serialised per device:
+// ew::resident_order); a launch that timed out leaves its half to be cleared by the next launch but one.
+// ---------------------------------------------------------------------------------------------
+template <int B, int E, class F> MI_DEV void ispf_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    ispf_static_for<B + 1, E>(f);
+  }
+}
+constexpr int ISPF_THREADS = 256;
+constexpr int ISPF_BPC = 2;               // blocks per CU: 8 waves per CU, up to 256 VGPRs each
+constexpr int ISPF_MAX_IMAGES = 64;
+constexpr int ISPF_SYNC_WORDS = ISPF_MAX_IMAGES * 8 * 16;   // per half: (image, XCD) -> 64 bytes {count, max bits, ...}
+struct IspFusedArgs {
+  int n_images, iters;                    // groups of 8 pixels per thread and image
+  int64_t n_groups;                       // per image: a multiple of 64 (whole waves)
+  float gamma_inv, intensity, la, ca;
+  const float* state9;
+  unsigned* sync;                         // this launch's half
+  unsigned* sync_next;                    // the other half: cleared here
+  unsigned spin_limit;
+  unsigned* fault;                        // the workspace's fault word
+  unsigned* mailbox;                      // host-mapped word of the device
+  struct IO { void* img; uint8_t* out; } io[ISPF_MAX_IMAGES];
+};
+
+template <class TI, bool CA0, int MAXIT, bool PIPE>
+__global__ __launch_bounds__(ISPF_THREADS, ISPF_BPC) void isp_reinhard_fused_kernel(const IspFusedArgs a) {
+#pragma clang fp contract(fast)
+  __shared__ float sh_fp[FP_COUNT];
+  __shared__ float sh_red[ISPF_THREADS / 64];
+  __shared__ float sh_max[2];
+  __shared__ __attribute__((aligned(16))) unsigned char io_buf[ISPF_THREADS / 64][64 * 24 * sizeof(TI)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  void* wbuf = io_buf[wave];
+  const int64_t stride = (int64_t)gridDim.x * ISPF_THREADS;
+  const int64_t tid = (int64_t)blockIdx.x * ISPF_THREADS + threadIdx.x;
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;     // XCC_ID: which XCD's words this block bumps
+
+  // the other half of the sync words, for the next launch (nobody reads it during this one)
+  for (int i = blockIdx.x * ISPF_THREADS + threadIdx.x; i < ISPF_SYNC_WORDS; i += gridDim.x * ISPF_THREADS) a.sync_next[i] = 0u;
+  if (threadIdx.x == 0) isp_reinhard_scalars(a.state9, sh_fp, a.intensity, a.ca);      // camera_isp.py:186-195
+  __syncthreads();
+  const float lo = sh_fp[FP_LO], inv = sh_fp[FP_INV];
+  ReinhardK rk;
+  rk.la = a.la; rk.ca = a.ca; rk.map_key = sh_fp[FP_MAPKEY]; rk.ei = sh_fp[FP_EI];
+  rk.mean3[0] = sh_fp[FP_MEAN3]; rk.mean3[1] = sh_fp[FP_MEAN3 + 1]; rk.mean3[2] = sh_fp[FP_MEAN3 + 2];
+
+  constexpr int SLOTS = PIPE ? 2 : 1;
+  Raw24<TI> keep[SLOTS][MAXIT];
+
+  // ---- P1: camera_isp.py:198-213 ----
+  auto p1 = [&](int k, auto slot_c) {
+    constexpr int S = decltype(slot_c)::value;
+    TI* img = static_cast<TI*>(a.io[k].img);
+    float vmax = -__builtin_inff();
+    constexpr bool PREFETCH = true;                          // the next group is asked for while this one is computed
+    Raw24<TI> raw;
+    if (PREFETCH && tid < a.n_groups) load24_raw<TI>(img + tid * 24, raw);
+    ispf_static_for<0, MAXIT>([&](auto itc) {
+      constexpr int IT = decltype(itc)::value;
+      const int64_t g = tid + IT * stride;
+      if (IT < a.iters && g < a.n_groups) {                  // (whole waves: n_groups and stride are multiples of 64)
+        float v[24], o[24];
+        if constexpr (!PREFETCH) load24_raw<TI>(img + g * 24, raw);
+        raw_to_float<TI>(raw, v);
+        if (PREFETCH && IT + 1 < a.iters && g + stride < a.n_groups) load24_raw<TI>(img + (g + stride) * 24, raw);
+#pragma unroll
+        for (int px = 0; px < 8; ++px) {
+          float t[3], q[3];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) t[ch] = (v[3 * px + ch] - lo) * inv;      // camera_isp.py:200: no clamp here
+          reinhard_px<CA0>(t, rk, q);
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) o[3 * px + ch] = q[ch];
+          vmax = fmaxf(vmax, fmaxf(q[0], fmaxf(q[1], q[2])));                       // of the un-rounded p (camera_isp.py:213)
+        }
+        // what pass 2 reads back: the ROUNDED p.  f16: packed pairs (v_cvt_pk_f16_f32 = RNE per element, the bits of
+        // cast_out<half_t>), made opaque - left to itself the compiler keeps every half in a register of its own
+        TI ot[24];
+        if constexpr (sizeof(TI) == 2) {
+          uint32_t w[12];
+#pragma unroll
+          for (int j = 0; j < 12; ++j) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w[j]) : "v"(o[2 * j]), "v"(o[2 * j + 1]));
+          __builtin_memcpy(&keep[S][IT], w, sizeof(w));
+          __builtin_memcpy(ot, w, sizeof(w));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 24; ++i) ot[i] = cast_out<TI>(o[i]);
+          __builtin_memcpy(&keep[S][IT], ot, sizeof(ot));
+        }
+        wave_store24<TI, false>(img + (g - lane) * 24, lane, wbuf, ot);            // camera_isp.py:211
+      }
+    });
+    // the block's maximum -> the image's word of this XCD, then the arrival
+    vmax = wave_max(vmax);
+    if (lane == 0) sh_red[wave] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = sh_red[0];
+#pragma unroll
+      for (int w = 1; w < ISPF_THREADS / 64; ++w) m = fmaxf(m, sh_red[w]);
+      m = fmaxf(m, 0.f);                                     // max_out = max(1e-6, .): negative maxima never matter; NaN dropped
+      unsigned* w2 = a.sync + ((unsigned)k * 8u + xcc) * 16u;
+      unsigned old = __hip_atomic_fetch_max(w2 + 1, __builtin_bit_cast(unsigned, m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) :: "memory");                 // the maximum is in before the arrival counts
+      __hip_atomic_fetch_add(w2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  };
+  // ---- W: max_out of image k (camera_isp.py:190,213) ----
+  auto wait_max = [&](int k) {
+    if (wave == 0) {
+      typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.sync, 0, ISPF_SYNC_WORDS * 4, 0x00020000);
+      const uint32_t off = lane < 8 ? ((uint32_t)k * 8u + (uint32_t)lane) * 64u : 0xFFFFFFFFu;
+      unsigned spins = 0;
+      float m = 0.f;
+      for (;;) {
+        const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 16);        // sc1: past this CU's L1 and the XCD's L2
+        unsigned cnt = lane < 8 ? t.x : 0u;
+        m = lane < 8 ? __builtin_bit_cast(float, t.y) : 0.f;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { cnt += __shfl_xor(cnt, o, 64); m = fmaxf(m, __shfl_xor(m, o, 64)); }
+        if (__builtin_amdgcn_readfirstlane(cnt) >= gridDim.x) break;
+        if (++spins > a.spin_limit) {
+          if (lane == 0) {
+            __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.mailbox) __hip_atomic_store(a.mailbox, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (lane == 0) sh_max[k & 1] = fmaxf(1e-6f, m);
+    }
+    __syncthreads();
+    return sh_max[k & 1];
+  };
+  // ---- P2: camera_isp.py:215-218 ----
+  auto p2 = [&](int k, auto slot_c, float max_out) {
+    constexpr int S = decltype(slot_c)::value;
+    uint8_t* out = a.io[k].out;
+    const float maxout_inv = 1.0f / max_out;
+    ispf_static_for<0, MAXIT>([&](auto itc) {
+      constexpr int IT = decltype(itc)::value;
+      const int64_t g = tid + IT * stride;
+      if (IT < a.iters && g < a.n_groups) {
+        float o[24];
+        raw_to_float<TI>(keep[S][IT], o);                    // (through an opaque copy of the packed words)
+#pragma unroll
+        for (int i = 0; i < 24; ++i) o[i] *= maxout_inv;
+        if (a.gamma_inv != 1.f) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < 24; ++j) o[j] = hw_pow(o[j], a.gamma_inv);
+        }
+        uint8_t ot[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) ot[i] = cast_out<uint8_t>(o[i] * 255.f);    // no clamp there; the cast saturates, NaN -> 0
+        wave_store24<uint8_t, true>(out + (g - lane) * 24, lane, wbuf, ot);
+      }
+    });
+  };
+
+  if constexpr (PIPE) {
+    // P1(0) P1(1) W(0) P2(0) P1(2) W(1) P2(1) ...: slots alternate, indices static
+    for (int k = 0; k < a.n_images; k += 2) {
+      p1(k, std::integral_constant<int, 0>{});
+      if (k >= 1) p2(k - 1, std::integral_constant<int, 1>{}, wait_max(k - 1));
+      if (k + 1 < a.n_images) p1(k + 1, std::integral_constant<int, 1>{});
+      p2(k, std::integral_constant<int, 0>{}, wait_max(k));
+    }
+    if ((a.n_images & 1) == 0) p2(a.n_images - 1, std::integral_constant<int, 1>{}, wait_max(a.n_images - 1));
+  } else {
+    for (int k = 0; k < a.n_images; ++k) {
+      p1(k, std::integral_constant<int, 0>{});
+      p2(k, std::integral_constant<int, 0>{}, wait_max(k));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ISP Reinhard pass 2 with the u8 result converted to planar YUV 4:2:0 on the way (the step after
 // the path for video encoders): per lane 2 rows x 8 pixels.  Exactly rgb_yuv420(u8 image of pass 2): the u8
 // values are formed (camera_isp.py:215-218), then fed to the conversion of color/yuv_420.py:39-66 - the u8 RGB
@@ -1893,6 +2093,104 @@ extern "C" int mi_isp_reinhard(void* image, uint8_t* out, int H, int W, int dtyp
   return launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s);
 }
 
+// mi_isp_reinhard_batch through isp_reinhard_fused_kernel when the group fits: no orientation transform, aligned whole
+// groups, every image's p resident (<= MAXIT groups per thread).  *done = false: the caller takes the two-pass path.
+static std::atomic<unsigned> g_ispf_poll_limit{0};
+static struct { unsigned* buf[16] = {}; unsigned launches[16] = {}; int bpc[8] = {-1, -1, -1, -1, -1, -1, -1, -1}; } g_ispf;
+template <class TI, bool CA0, int MAXIT, bool PIPE>
+static int ispf_launch(const IspFusedArgs& a, int nblocks, int slot, hipStream_t s, bool* ok) {
+  if (g_ispf.bpc[slot] < 0) {
+    int per_cu = 0;
+    MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE>, ISPF_THREADS, 0));
+    g_ispf.bpc[slot] = per_cu;
+  }
+  *ok = g_ispf.bpc[slot] >= ISPF_BPC;                        // every block resident, or not at all
+  if (!*ok) return 0;
+  hipLaunchKernelGGL((isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE>), dim3(nblocks), dim3(ISPF_THREADS), 0, s, a);
+  MI_LAUNCH_CHECK();
+  return 0;
+}
+static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, int H, int W, int dtype, const float* state9,
+                              float gamma, float intensity, float la, float ca, int transform, float* fp, hipStream_t s,
+                              bool* done) {
+  *done = false;
+  const char* env = getenv("MI_ISP_REINHARD_LAUNCHES");        // (read per call: =2 forces the two-pass path - tests, A/B)
+  if (env && atoi(env) == 2) return 0;
+  if (transform != MI_T_NONE || m < 1 || m > ISPF_MAX_IMAGES) return 0;
+  const int64_t n_px = (int64_t)H * W;
+  if (n_px % 512 != 0) return 0;                               // whole waves of whole groups only
+  for (int i = 0; i < m; ++i)
+    if (!vec_ok(images[i], dtype) || !mi_aligned(outs[i], 16)) return 0;
+  int dev = 0, n_cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus < 1) return 0;
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap_status);
+  if (cap_status != hipStreamCaptureStatusNone) return 0;      // (a capture cannot be put in order)
+  const int64_t n_groups = n_px / 8;
+  int nblocks = n_cus * ISPF_BPC;
+  if ((int64_t)nblocks * ISPF_THREADS > n_groups) nblocks = (int)(n_groups / ISPF_THREADS) > 0 ? (int)(n_groups / ISPF_THREADS) : 1;
+  const int iters = (int)((n_groups + (int64_t)nblocks * ISPF_THREADS - 1) / ((int64_t)nblocks * ISPF_THREADS));
+  const bool f16 = dtype == MI_F16;
+  const bool pipe = iters <= 3 && m > 1;
+  if (!pipe && iters > 6) return 0;                          // (a 12-group variant for 4096 x 3072 f16 frames spilled 20 - 170 registers)
+  IspFusedArgs a = {};
+  a.n_images = m; a.iters = iters; a.n_groups = n_groups;
+  a.gamma_inv = (float)(1.0 / (double)gamma); a.intensity = intensity; a.la = la; a.ca = ca; a.state9 = state9;
+  const unsigned limit = g_ispf_poll_limit.load(std::memory_order_relaxed);
+  a.spin_limit = limit ? limit - 1u : 2000000u;
+  a.fault = reinterpret_cast<unsigned*>(fp) + 62;              // FP_ERROR
+  for (int i = 0; i < m; ++i) { a.io[i].img = images[i]; a.io[i].out = outs[i]; }
+  ew::ResidentOrder& ord = ew::resident_order();
+  std::lock_guard<std::mutex> lock(ord.mu);
+  if (!g_ispf.buf[dev]) {
+    void* d = nullptr;
+    MI_HIP(hipMalloc(&d, (size_t)2 * ISPF_SYNC_WORDS * 4));
+    MI_HIP(hipMemset(d, 0, (size_t)2 * ISPF_SYNC_WORDS * 4));
+    g_ispf.buf[dev] = static_cast<unsigned*>(d);
+  }
+  if (int rc = ew::resident_enter_locked(dev, s)) return rc;
+  const unsigned half = g_ispf.launches[dev] & 1u;
+  a.sync = g_ispf.buf[dev] + half * ISPF_SYNC_WORDS;
+  a.sync_next = g_ispf.buf[dev] + (half ^ 1u) * ISPF_SYNC_WORDS;
+  a.mailbox = ord.mailbox_dev[dev] + ew::MAILBOX_ISP_TONEMAP;
+  bool ok = false;
+  int rc = 0;
+  const bool ca0 = ca == 0.f;
+  const int slot = (f16 ? 0 : 4) + (ca0 ? 0 : 2) + (pipe ? 0 : 1);
+#define MI_ISPF(TI, CA0, MAXIT, PIPE) rc = ispf_launch<TI, CA0, MAXIT, PIPE>(a, nblocks, slot, s, &ok)
+  if (f16) {
+    if (ca0) { if (pipe) MI_ISPF(half_t, true, 3, true); else MI_ISPF(half_t, true, 6, false); }
+    else     { if (pipe) MI_ISPF(half_t, false, 3, true); else MI_ISPF(half_t, false, 6, false); }
+  } else {
+    if (ca0) { if (pipe) MI_ISPF(float, true, 3, true); else MI_ISPF(float, true, 6, false); }
+    else     { if (pipe) MI_ISPF(float, false, 3, true); else MI_ISPF(float, false, 6, false); }
+  }
+#undef MI_ISPF
+  if (rc || !ok) return rc;
+  ++g_ispf.launches[dev];
+  if (int rc2 = ew::resident_leave_locked(dev, s)) return rc2;
+  *done = true;
+  return 0;
+}
+
+extern "C" int mi_isp_reinhard_set_poll_limit(unsigned polls) {
+  g_ispf_poll_limit.store(polls, std::memory_order_relaxed);
+  return 0;
+}
+// the fused ISP tonemap's mailbox word of the current device (see mi_isp_metering_faults)
+extern "C" int mi_isp_reinhard_faults(int clear) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  ew::ResidentOrder& ord = ew::resident_order();
+  std::lock_guard<std::mutex> lock(ord.mu);
+  if (!ord.mailbox_host[dev]) return 0;
+  volatile unsigned* mb = ord.mailbox_host[dev] + ew::MAILBOX_ISP_TONEMAP;
+  const unsigned v = *mb;
+  if (clear) *mb = 0;
+  return (int)v;
+}
+
 // N images of one tonemap_reinhard call (camera_isp.py:399-403) with 4 launches in total instead of
 // 4 per image: prep, pass 1 over all images (grid.y = image), per-image max_out, pass 2 over all.
 extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
@@ -1912,6 +2210,14 @@ extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, 
   if (n == 0) return 0;
   for (int i0 = 0; i0 < n; i0 += 64) {
     const int m = n - i0 < 64 ? n - i0 : 64;
+    {
+      for (int i = 0; i < m; ++i) MI_REQUIRE(images[i0 + i] && outs[i0 + i], "reinhard_batch: image %d is null", i0 + i);
+      bool done = false;                                       // one persistent launch when the group's p fits the chip
+      if (int rc = isp_reinhard_fused(images + i0, outs + i0, m, H, W, dtype, state9, gamma, intensity, light_adapt,
+                                      color_adapt, transform, fp, s, &done))
+        return rc;
+      if (done) continue;
+    }
     PassArgs a = {};
     a.fp = fp; a.partials = partials; a.part_stride = cap; a.n_px = (int64_t)H * W;
     a.vec_in = 1; a.vec_out = 1;

@@ -806,6 +806,80 @@ def test_isp_metering_timeout_leaves_the_state_alone(ti, dev):
     assert_close(isp.metrics.cpu().numpy(), st.update_metering(refs), "metrics after the failed call", rel=2e-5)
 
 
+@pytest.mark.parametrize("cam,shape,n,kw", [("Camera16", (48, 64), 1, dict(gamma=0.6)), ("Camera16", (96, 128), 2, dict()),
+                                            ("Camera16", (200, 512), 3, dict(gamma=0.8, intensity=1.3, light_adapt=0.7)),
+                                            ("Camera32", (96, 128), 7, dict(gamma=0.6)),
+                                            ("Camera16", (768, 1024), 6, dict(gamma=0.6, color_adapt=0.4)),
+                                            ("Camera32", (768, 1024), 4, dict(gamma=2.2, color_adapt=0.3, light_adapt=0.5))])
+def test_isp_reinhard_in_one_launch_equals_two_passes(ti, dev, cam, shape, n, kw, monkeypatch):
+    """mi_isp_reinhard_batch as one persistent launch (p kept on chip between the two passes of camera_isp.py:198-218,
+    the images' max_out exchanged through per-XCD words) against the two launches it replaces: in-place p and u8 outputs
+    bit for bit - one image, pairs, odd counts (the pipeline's tail), both dtypes, color_adapt != 0 - and against the oracle."""
+    from oracle import c_oracle
+    H, W = shape
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(700 + k), H, W, dark=0.03 * k)).to(dev) for k in range(n)]
+
+    def run(two_pass):
+        if two_pass:
+            monkeypatch.setenv("MI_ISP_REINHARD_LAUNCHES", "2")
+        else:
+            monkeypatch.delenv("MI_ISP_REINHARD_LAUNCHES", raising=False)
+        isp = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.4, device=dev)
+        res = []
+        for step in range(2):
+            imgs = [isp.load_packed12(f) for f in frames]
+            before = [im.clone() for im in imgs]
+            outs = isp.tonemap_reinhard(imgs, **kw)
+            res.append((before, [im.clone() for im in imgs], [o.clone() for o in outs], isp.metrics.clone()))
+        torch.cuda.synchronize()
+        return res
+    one, two = run(False), run(True)
+    for step in range(2):
+        assert torch.equal(one[step][3], two[step][3])
+        for k in range(n):
+            assert torch.equal(one[step][1][k], two[step][1][k]), f"step {step} image {k}: in-place p differs"
+            assert torch.equal(one[step][2][k], two[step][2][k]), f"step {step} image {k}: u8 output differs"
+    if c_oracle.available():
+        before, after, outs, metrics = one[1]
+        ref_u8, ref_after = c_oracle.reinhard_isp(before[n - 1].cpu().numpy(), metrics.cpu().numpy(), **kw)
+        assert_close(outs[n - 1].cpu().numpy(), ref_u8, "u8 against the oracle")
+        assert_close(after[n - 1].cpu().numpy(), ref_after, "in-place p against the oracle")
+    from taichi_image_amd import _native
+    assert _native.lib().mi_isp_reinhard_faults(1) == 0
+
+
+def test_isp_reinhard_one_launch_timeout_is_reported(ti, dev):
+    """The fused tonemap's wait for max_out with a budget of one poll: a block that looks before the others have arrived
+    gives up - fault word, mailbox, TonemapTimeout at the next call - and nothing hangs; the call after that is clean."""
+    from taichi_image_amd import _native
+    from taichi_image_amd.camera_isp import TonemapTimeout
+    L = _native.lib()
+    H, W = 768, 1024
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(800 + k), H, W)).to(dev) for k in range(4)]
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.4, device=dev)
+    good = isp.tonemap_reinhard([isp.load_packed12(f) for f in frames], gamma=0.6)
+    torch.cuda.synchronize()
+    assert L.mi_isp_reinhard_faults(1) == 0
+    L.mi_isp_reinhard_set_poll_limit(1)
+    try:
+        # (one image: its wait follows its own pass at once - in the pipelined form a whole pass of the next image lies
+        # between, and every block has usually arrived by then)
+        isp.tonemap_reinhard([isp.load_packed12(frames[0])], gamma=0.6)
+        torch.cuda.synchronize()
+    finally:
+        L.mi_isp_reinhard_set_poll_limit(0)
+    assert L.mi_isp_reinhard_faults(0) != 0
+    ws = _native.workspace(H, W, dev)
+    off = int(L.mi_isp_workspace_error_offset(H, W))
+    assert int(ws[off:off + 4].view(torch.int32).item()) != 0
+    ws[off:off + 4].zero_()
+    with pytest.raises(TonemapTimeout):
+        isp.update_metering([isp.load_packed12(frames[0])])
+    isp2 = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.4, device=dev)
+    again = isp2.tonemap_reinhard([isp2.load_packed12(f) for f in frames], gamma=0.6)
+    assert all(torch.equal(a, b) for a, b in zip(again, good)) and L.mi_isp_reinhard_faults(0) == 0
+
+
 def test_resident_grids_of_both_kinds_share_one_order(ti, dev):
     """A one-launch metering grid and a whole-frame grid on two streams: each needs all its blocks resident, so the library
     puts them in ONE order (round 3 kept two, and the two kinds could hold half of the chip each until their budgets ran
