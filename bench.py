@@ -10,7 +10,11 @@ reference's test/pipeline.py:26-32), `--frames` frames per rank per step (defaul
 batch).  Headline chain: the whole-frame kernel (csrc/isp_mega.h), ONE launch per step - the resident
 grid walks through the 64 frames.  (--chain multi-pass: the streaming chain, one frame per HIP stream
 in flight, the step replayed as a HIP graph captured inside the library.)  Frames are independent, so
-N ranks shard the batch with no data-path collective ("scaling": "weak": per-GPU work is fixed).
+N ranks shard the batch with no data-path collective.  --scaling weak (default; "scaling": "weak"): every rank
+processes --frames frames per step, per-GPU work is fixed; --scaling strong: --frames frames per step in TOTAL,
+--frames / N per rank - BASELINE config 4's literal shape (64 frames over 8 GPUs = 8 frames per launch, so the
+~14 us a launch costs weigh 1.7 us per frame instead of 0.2).  The line says which one ran, which backend the process
+group has, how many ranks IT counts, and the fastest / slowest rank's own time per frame.
 Inputs are resident in HBM before the timed region; value = total megapixels (sensor pixels) of all
 ranks / max-over-ranks wall time.
 
@@ -116,13 +120,48 @@ def cpu_baseline(packed_frame: np.ndarray):
                       f"(oracle/isp_oracle.py), host has {ncores} cores"}
 
 
+def host_frames(first, count, distinct):
+    """`distinct` different synthetic frames (seeds 1234 + index), generated on a thread pool (3 s of numpy
+    each), cycled over `count` slots.  Returns (list of the distinct host frames, index of every slot)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from taichi_image_amd import synthetic
+    distinct = max(1, min(distinct, count))
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 4, distinct)) as ex:
+        host = list(ex.map(lambda i: synthetic.synthetic_packed12((first + i) % 64), range(distinct)))
+    return host, [i % distinct for i in range(count)]
+
+
+def rank_stats(elapsed_local, frames_local, steps, world, device):
+    """Every rank's own time for its share (local synchronisation, before the ranks' barrier): us per frame of the
+    fastest and the slowest rank - what tells a straggler from a uniformly slow run in the driver's 8-GPU line."""
+    us = elapsed_local / max(1, frames_local * steps) * 1e6
+    if world == 1:
+        return {"min": round(us, 2), "max": round(us, 2)}
+    import torch.distributed as dist
+    t = torch.tensor([us], dtype=torch.float64, device=reduce_device(device))
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    vals = [float(p.item()) for p in parts]
+    return {"min": round(min(vals), 2), "max": round(max(vals), 2), "per_rank": [round(v, 2) for v in vals]}
+
+
+def run_identity(world, backend):
+    """Who took part: the backend of the process group and the number of ranks IT reports (not the --gpus argument)."""
+    if world > 1:
+        import torch.distributed as dist
+        return {"backend": "rccl (torch.distributed 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend(),
+                "ranks_seen": dist.get_world_size()}
+    return {"backend": "none (single process)", "ranks_seen": 1}
+
+
 def reduce_device(device):
     """Where the max-over-ranks timing tensor lives: the GPU under RCCL, the host in a gloo rehearsal."""
     return torch.device("cpu") if os.environ.get("MI_ISP_BENCH_BACKEND", "nccl") == "gloo" else device
 
 
-def timed(fn, steps, warmup, device, barrier=None):
-    """`steps` calls of fn bracketed by synchronisation (and the ranks' barrier); seconds."""
+def timed(fn, steps, warmup, device, barrier=None, local=None):
+    """`steps` calls of fn bracketed by synchronisation (and the ranks' barrier); seconds.  local: a list that receives this
+    rank's own time (its device synchronised, before the barrier)."""
     sync = barrier or (lambda: torch.cuda.synchronize(device))
     for _ in range(warmup):
         fn()
@@ -130,6 +169,9 @@ def timed(fn, steps, warmup, device, barrier=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    if local is not None:
+        torch.cuda.synchronize(device)
+        local.append(time.perf_counter() - t0)
     sync()
     return time.perf_counter() - t0
 
@@ -147,8 +189,8 @@ def isp_workload(args, rank, world, device):
     from taichi_image_amd import synthetic
     shared = args.workload == "isp-shared-stats"
     group = dist.group.WORLD if (shared and world > 1) else None
-    host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(min(4, args.frames))]
-    frames = [torch.from_numpy(host[i % len(host)]).to(device) for i in range(args.frames)]
+    host, slot = host_frames(rank * args.frames, args.frames, min(4, args.frames))
+    frames = [torch.from_numpy(host[slot[i]]).to(device) for i in range(args.frames)]
     step = isp_step_fn(frames, device, group)
 
     def barrier():
@@ -157,18 +199,38 @@ def isp_workload(args, rank, world, device):
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    elapsed = timed(step, args.steps, args.warmup, device, barrier)
+    from taichi_image_amd import distributed as tdist
+    local = []
+    elapsed = timed(step, args.steps, args.warmup, device, barrier, local)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    per_rank = rank_stats(local[0], args.frames, args.steps, world, device)
+    # what the two collectives of a step cost (config 5): HIP events around every all-gather of a few extra steps BEHIND
+    # the timed region (events between launches are not free)
+    collective_us = None
+    if group is not None:
+        tdist.collective_events = []
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize(device)
+        ev = tdist.collective_events
+        tdist.collective_events = None
+        if ev:
+            collective_us = round(sum(e0.elapsed_time(e1) for e0, e1 in ev) * 1e3 / 8, 2)
     if rank == 0:
         out_bytes = 1440 * 1920 * 3
         print(json.dumps({
+            **run_identity(world, os.environ.get("MI_ISP_BENCH_BACKEND", "nccl")),
+            "us_per_frame_by_rank": per_rank,
+            "collective_us_per_step": collective_us,
+            "collective_note": ("two all-gathers per update_metering (2 + 8 floats per rank), HIP events on the compute stream, "
+                                "average over 8 steps behind the timed region" if collective_us is not None else None),
             "metric": METRIC,
             "value": round(world * args.frames * args.steps * MP / elapsed, 1), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("config 5" if shared else "config 3") + ": Camera16(RGGB, resize_width=1920, "
                        "moving_alpha=0.1) load_packed12 x frames + tonemap_reinhard(gamma=0.6) -> u8 1920x1440"
                        + (", metering all-reduced over ranks (RCCL)" if shared else ""),
@@ -218,7 +280,7 @@ def other_workloads(frames, host, device, frames_per_step):
         return pack12(v)
     # frames whose demosaiced bounds are NOT (0, 1): the statistics phase / pass runs (no data-dependent
     # shortcut); scene scaled into [0.1, 0.8]
-    nu_dev = [torch.from_numpy(rescale(host[i])).to(device) for i in range(len(host))]
+    nu_dev = [torch.from_numpy(rescale(host[i])).to(device) for i in range(min(4, len(host)))]
     nonunit = [nu_dev[i % len(nu_dev)] for i in range(len(frames))]
     wf_steps = max(4, 1200 // max(1, len(frames)))         # ~60 ms per run at 64 frames per step
     # config 2 with the u8 output of the ISP semantics (4.5 B/px), through the headline chain
@@ -332,6 +394,11 @@ def main():
                     help="config 2 through the single-launch whole-frame kernel (csrc/isp_mega.h; frames one after the "
                          "other) or through the multi-pass streaming chain (frames on --streams streams); auto = the "
                          "whole-frame kernel when the frame fits it")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --frames frames per RANK per step, the batch grows with N; strong: --frames frames per "
+                         "step in TOTAL, --frames / N per rank (BASELINE config 4's literal shape: 64 frames over 8 GPUs)")
+    ap.add_argument("--distinct", type=int, default=None,
+                    help="distinct synthetic frames per rank (default: every frame of the step its own scene, seeds 1234 + k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true",
                     help="skip the single-frame launches behind the timed region (profiling: every launch the profiler sees "
@@ -357,6 +424,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    frames_total = args.frames * world if args.scaling == "weak" else args.frames
+    if args.scaling == "strong":
+        assert args.frames % world == 0, f"--scaling strong: --frames {args.frames} must be a multiple of --gpus {world}"
+        args.frames //= world                        # from here on: frames per rank and step
     if not torch.cuda.is_available():
         print(f"bench.py rank {rank}/{world}: needs a GPU (there is no CPU fallback)", file=sys.stderr, flush=True)
         sys.exit(3)
@@ -379,10 +450,12 @@ def main():
     if isp:
         return isp_workload(args, rank, world, device)
 
-    # distinct synthetic frames per rank (seeds 1234 + k); 4 distinct, cycled
-    n_distinct = min(4, args.frames)
-    host = [synthetic.synthetic_packed12((rank * args.frames + i) % 64) for i in range(n_distinct)]
-    frames = [torch.from_numpy(host[i % n_distinct]).to(device) for i in range(args.frames)]
+    # synthetic frames of this rank (frame k of the batch is scene k, seed 1234 + k): every frame its own
+    # scene unless --distinct asks for fewer (cycled)
+    n_distinct = min(args.frames, args.distinct if args.distinct else args.frames)
+    host, slot = host_frames(rank * args.frames, args.frames, n_distinct)
+    dev_distinct = [torch.from_numpy(h).to(device) for h in host]
+    frames = [dev_distinct[slot[i]] if n_distinct < args.frames else dev_distinct[i] for i in range(args.frames)]
     use_graph = not args.no_graph
     from taichi_image_amd import types as _types
     from taichi_image_amd.pipeline import whole_frame_fits
@@ -413,19 +486,22 @@ def main():
     t0 = time.perf_counter()
     for step in range(args.steps):
         bp(frames, eager=(not use_graph) or (step % max(1, args.eager_every) == 0))
+    torch.cuda.synchronize(device)
+    elapsed_local = time.perf_counter() - t0          # this rank's own time, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     live_us, live_n = (ctypes.c_float * 4)(), ctypes.c_int(0)
     _native.check(_native.lib().mi_isp_profile_collect(live_us, ctypes.byref(live_n)))
     _native.check(_native.lib().mi_isp_profile_enable(0, 1))
     faults = len(bp.check(frames)) if whole else 0          # after the timed region: every output valid, or repaired and counted
+    per_rank = rank_stats(elapsed_local, args.frames, args.steps, world, device)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device(device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        total_mp = world * args.frames * args.steps * MP
+        total_mp = frames_total * args.steps * MP
         value = total_mp / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         live = [float(v) for v in live_us]            # in-situ averages over the timed region
@@ -462,10 +538,19 @@ def main():
         line = {
             "metric": METRIC,
             "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            **run_identity(world, backend),
+            "us_per_frame_by_rank": per_rank,
             "config": {"workload": "config 2: 4096x3072 packed-12 RGGB -> demosaic -> Reinhard tonemap (stateless, "
                                    "gamma 1) -> f16 RGB", "frames_per_rank_per_step": args.frames,
+                       "frames_per_step_all_ranks": frames_total,
+                       "scaling_mode": ("weak: every rank processes --frames frames per step" if args.scaling == "weak" else
+                                        "strong: --frames frames per step in total, split evenly over the ranks (BASELINE config 4: "
+                                        "64 frames over 8 GPUs = 8 per launch)"),
+                       "distinct_frames_per_rank": n_distinct,
+                       "frame_seeds": f"1234 + (rank * frames_per_rank + i) % 64, i < {n_distinct} (SURVEY 8(d))"
+                                      + ("" if n_distinct == args.frames else f", cycled over the {args.frames} buffers"),
                        "streams_per_rank": 1 if whole else args.streams, "work_dtype": "f16",
                        "chain": ("whole-frame kernel: one persistent launch per step (csrc/isp_mega.h), the resident grid walks "
                                  "through the step's frames" if whole else
@@ -476,7 +561,7 @@ def main():
                        "sharding": f"frames x{world}, no collective"},
             "us_per_frame": round(elapsed / (args.frames * args.steps) * 1e6, 2),
             "timed_region_s": round(elapsed, 3),
-            "pipeline_frac_of_hbm_roofline": round(ALG_BYTES * world * args.frames * args.steps / elapsed / 1e9
+            "pipeline_frac_of_hbm_roofline": round(ALG_BYTES * frames_total * args.steps / elapsed / 1e9
                                                    / (HBM_PEAK_GBS * world), 4),
             "roofline": {"bound": "hbm", "kernel": names[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -497,6 +582,12 @@ def main():
         if world == 1 and not args.no_other_workloads:
             del bp
             line["other_workloads"] = other_workloads(frames, host, device, args.frames)
+            # the same kernel on frames whose bounds are not (0, 1) - what a sensor with a black level delivers: no
+            # data-dependent shortcut (phase B and its barrier run)
+            gp = line["other_workloads"].get("config2_whole_frame_kernel_bounds_not_unit")
+            if gp and whole:
+                line["roofline"]["general_path_frac"] = gp["frac_of_hbm_roofline"]
+                line["roofline"]["general_path_us_per_frame"] = gp["us_per_frame"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host[0])
         else:

@@ -276,11 +276,12 @@ int mi_isp_whole_frame_set_sabotage(int block);
  * mi_isp_metering_set_poll_limit(polls): poll budget of the following launches (0 = default, ~1 s; tests use 1). */
 int mi_isp_metering_faults(int clear);
 int mi_isp_metering_set_poll_limit(unsigned polls);
-/* mi_isp_reinhard_batch (reinhard_kernel of camera_isp.py:177-218 for a list of images) runs as ONE persistent launch
- * when no orientation transform is asked for, the buffers are 16-byte aligned, H * W is a multiple of 512 and an image's
- * mapped values fit the chip's registers (up to 3.1 MP per image pipelined, 6.3 MP one at a time): p is written in place
- * as the reference does (camera_isp.py:211) and kept on chip for the second pass, whose re-read and launch disappear.
- * Same results as the two launches (MI_ISP_REINHARD_LAUNCHES=2 in the environment forces those), bit for bit.
+/* Experimental (off by default; MI_ISP_REINHARD_LAUNCHES=1 in the environment enables it): mi_isp_reinhard_batch
+ * (reinhard_kernel of camera_isp.py:177-218 for a list of images) as ONE persistent launch when no orientation transform
+ * is asked for, the buffers are 16-byte aligned, H * W is a multiple of 512 and an image's mapped values fit the chip's
+ * registers (up to 3.1 MP per image pipelined, 6.3 MP one at a time): p is written in place as the reference does
+ * (camera_isp.py:211) and kept on chip for the second pass.  Same results as the two launches, bit for bit; measured
+ * slower than them, hence off.
  * Its one grid-wide wait (max_out, camera_isp.py:213) can time out like the others: fault word of the workspace +
  * mi_isp_reinhard_faults(clear), the device's mailbox word of this kernel (a plain host read); the outputs of that call
  * are then invalid.  mi_isp_reinhard_set_poll_limit(polls): poll budget of the following launches (0 = default). */

@@ -860,7 +860,7 @@ template <int B, int E, class F> MI_DEV void ispf_static_for(F&& f) {
   }
 }
 constexpr int ISPF_THREADS = 256;
-constexpr int ISPF_BPC = 2;               // blocks per CU: 8 waves per CU, up to 256 VGPRs each
+constexpr int ISPF_BPC = 2;               // blocks per CU: 8 waves per CU, up to 256 VGPRs each (16 waves, 128 VGPRs: the BPC = 4 variant)
 constexpr int ISPF_MAX_IMAGES = 64;
 constexpr int ISPF_SYNC_WORDS = ISPF_MAX_IMAGES * 8 * 16;   // per half: (image, XCD) -> 64 bytes {count, max bits, ...}
 struct IspFusedArgs {
@@ -876,8 +876,8 @@ struct IspFusedArgs {
   struct IO { void* img; uint8_t* out; } io[ISPF_MAX_IMAGES];
 };
 
-template <class TI, bool CA0, int MAXIT, bool PIPE>
-__global__ __launch_bounds__(ISPF_THREADS, ISPF_BPC) void isp_reinhard_fused_kernel(const IspFusedArgs a) {
+template <class TI, bool CA0, int MAXIT, bool PIPE, int BPC>
+__global__ __launch_bounds__(ISPF_THREADS, BPC) void isp_reinhard_fused_kernel(const IspFusedArgs a) {
 #pragma clang fp contract(fast)
   __shared__ float sh_fp[FP_COUNT];
   __shared__ float sh_red[ISPF_THREADS / 64];
@@ -900,23 +900,26 @@ __global__ __launch_bounds__(ISPF_THREADS, ISPF_BPC) void isp_reinhard_fused_ker
 
   constexpr int SLOTS = PIPE ? 2 : 1;
   Raw24<TI> keep[SLOTS][MAXIT];
+  Raw24<TI> raw;                                             // the group in flight (see p1)
+  if (tid < a.n_groups) load24_raw<TI>(static_cast<const TI*>(a.io[0].img) + tid * 24, raw);
 
   // ---- P1: camera_isp.py:198-213 ----
   auto p1 = [&](int k, auto slot_c) {
     constexpr int S = decltype(slot_c)::value;
     TI* img = static_cast<TI*>(a.io[k].img);
+    const TI* img_next = static_cast<const TI*>(a.io[k + 1 < a.n_images ? k + 1 : k].img);
     float vmax = -__builtin_inff();
-    constexpr bool PREFETCH = true;                          // the next group is asked for while this one is computed
-    Raw24<TI> raw;
-    if (PREFETCH && tid < a.n_groups) load24_raw<TI>(img + tid * 24, raw);
+    // `raw` holds this image's first group already (asked for during the previous image's pass: a thread has only two or
+    // three groups per image, and a first load that starts with the pass is ~1.5 us of exposed latency per image)
     ispf_static_for<0, MAXIT>([&](auto itc) {
       constexpr int IT = decltype(itc)::value;
       const int64_t g = tid + IT * stride;
       if (IT < a.iters && g < a.n_groups) {                  // (whole waves: n_groups and stride are multiples of 64)
         float v[24], o[24];
-        if constexpr (!PREFETCH) load24_raw<TI>(img + g * 24, raw);
         raw_to_float<TI>(raw, v);
-        if (PREFETCH && IT + 1 < a.iters && g + stride < a.n_groups) load24_raw<TI>(img + (g + stride) * 24, raw);
+        // the next group is asked for while this one is computed: of this image, or the first one of the next image
+        if (IT + 1 < a.iters && g + stride < a.n_groups) load24_raw<TI>(img + (g + stride) * 24, raw);
+        else if (k + 1 < a.n_images) load24_raw<TI>(img_next + tid * 24, raw);
 #pragma unroll
         for (int px = 0; px < 8; ++px) {
           float t[3], q[3];
@@ -963,15 +966,19 @@ __global__ __launch_bounds__(ISPF_THREADS, ISPF_BPC) void isp_reinhard_fused_ker
   // ---- W: max_out of image k (camera_isp.py:190,213) ----
   auto wait_max = [&](int k) {
     if (wave == 0) {
-      typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.sync, 0, ISPF_SYNC_WORDS * 4, 0x00020000);
       const uint32_t off = lane < 8 ? ((uint32_t)k * 8u + (uint32_t)lane) * 64u : 0xFFFFFFFFu;
       unsigned spins = 0;
       float m = 0.f;
       for (;;) {
-        const u2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 16);        // sc1: past this CU's L1 and the XCD's L2
-        unsigned cnt = lane < 8 ? t.x : 0u;
-        m = lane < 8 ? __builtin_bit_cast(float, t.y) : 0.f;
+        // sc1: past this CU's L1.  (A 16-byte load whose words are copied out by name: hipcc 7.2 turned the 8-byte form
+        // into ONE dword load and used the count for the maximum as well - the .x-for-.y defect of the metering kernel.)
+        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        uint32_t tx = t.x, ty = t.y;
+        asm volatile("" : "+v"(tx), "+v"(ty));
+        unsigned cnt = lane < 8 ? tx : 0u;
+        m = lane < 8 ? __builtin_bit_cast(float, ty) : 0.f;
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) { cnt += __shfl_xor(cnt, o, 64); m = fmaxf(m, __shfl_xor(m, o, 64)); }
         if (__builtin_amdgcn_readfirstlane(cnt) >= gridDim.x) break;
@@ -2096,17 +2103,17 @@ extern "C" int mi_isp_reinhard(void* image, uint8_t* out, int H, int W, int dtyp
 // mi_isp_reinhard_batch through isp_reinhard_fused_kernel when the group fits: no orientation transform, aligned whole
 // groups, every image's p resident (<= MAXIT groups per thread).  *done = false: the caller takes the two-pass path.
 static std::atomic<unsigned> g_ispf_poll_limit{0};
-static struct { unsigned* buf[16] = {}; unsigned launches[16] = {}; int bpc[8] = {-1, -1, -1, -1, -1, -1, -1, -1}; } g_ispf;
-template <class TI, bool CA0, int MAXIT, bool PIPE>
+static struct { unsigned* buf[16] = {}; unsigned launches[16] = {}; int bpc[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}; } g_ispf;
+template <class TI, bool CA0, int MAXIT, bool PIPE, int BPC>
 static int ispf_launch(const IspFusedArgs& a, int nblocks, int slot, hipStream_t s, bool* ok) {
   if (g_ispf.bpc[slot] < 0) {
     int per_cu = 0;
-    MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE>, ISPF_THREADS, 0));
+    MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE, BPC>, ISPF_THREADS, 0));
     g_ispf.bpc[slot] = per_cu;
   }
-  *ok = g_ispf.bpc[slot] >= ISPF_BPC;                        // every block resident, or not at all
+  *ok = g_ispf.bpc[slot] >= BPC;                             // every block resident, or not at all
   if (!*ok) return 0;
-  hipLaunchKernelGGL((isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE>), dim3(nblocks), dim3(ISPF_THREADS), 0, s, a);
+  hipLaunchKernelGGL((isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE, BPC>), dim3(nblocks), dim3(ISPF_THREADS), 0, s, a);
   MI_LAUNCH_CHECK();
   return 0;
 }
@@ -2114,8 +2121,14 @@ static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, 
                               float gamma, float intensity, float la, float ca, int transform, float* fp, hipStream_t s,
                               bool* done) {
   *done = false;
-  const char* env = getenv("MI_ISP_REINHARD_LAUNCHES");        // (read per call: =2 forces the two-pass path - tests, A/B)
-  if (env && atoi(env) == 2) return 0;
+  // MEASURED (round 4, 6 x 1440 x 1920 f16, gamma 0.6): bit-identical to the two passes and SLOWER - 0.267 - 0.272 ms per
+  // 6-camera step against 0.257 (scripts/time_isp.py).  The two passes move 350 MB at 5.5 TB/s: they are at the memory's
+  // practical rate, and the 100 MB this kernel saves do not pay for what it loses - 11 transcendentals per pixel in
+  // dependent chains on 8 - 16 waves per CU instead of 32, two or three groups per thread and image (nothing to pipeline
+  // within an image), and a block-wide hand-over per image.  So it is OFF unless MI_ISP_REINHARD_LAUNCHES=1 asks for it
+  // (read per call; tests/ compare the two paths bit for bit).
+  const char* env = getenv("MI_ISP_REINHARD_LAUNCHES");
+  if (!(env && atoi(env) == 1)) return 0;
   if (transform != MI_T_NONE || m < 1 || m > ISPF_MAX_IMAGES) return 0;
   const int64_t n_px = (int64_t)H * W;
   if (n_px % 512 != 0) return 0;                               // whole waves of whole groups only
@@ -2128,12 +2141,14 @@ static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, 
   (void)hipStreamIsCapturing(s, &cap_status);
   if (cap_status != hipStreamCaptureStatusNone) return 0;      // (a capture cannot be put in order)
   const int64_t n_groups = n_px / 8;
+  const bool f16 = dtype == MI_F16;
+  // (Four blocks per CU - 16 waves, <= 128 VGPRs, two kept groups per image and thread - measured no faster: 0.272 against
+  // 0.267 ms per step, and it spilled 9 - 13 registers once the next image's first group was prefetched.  Taken out.)
   int nblocks = n_cus * ISPF_BPC;
   if ((int64_t)nblocks * ISPF_THREADS > n_groups) nblocks = (int)(n_groups / ISPF_THREADS) > 0 ? (int)(n_groups / ISPF_THREADS) : 1;
   const int iters = (int)((n_groups + (int64_t)nblocks * ISPF_THREADS - 1) / ((int64_t)nblocks * ISPF_THREADS));
-  const bool f16 = dtype == MI_F16;
   const bool pipe = iters <= 3 && m > 1;
-  if (!pipe && iters > 6) return 0;                          // (a 12-group variant for 4096 x 3072 f16 frames spilled 20 - 170 registers)
+  if (!pipe && iters > (f16 ? 6 : 4)) return 0;              // (what the registers hold next to the working set)
   IspFusedArgs a = {};
   a.n_images = m; a.iters = iters; a.n_groups = n_groups;
   a.gamma_inv = (float)(1.0 / (double)gamma); a.intensity = intensity; a.la = la; a.ca = ca; a.state9 = state9;
@@ -2158,13 +2173,13 @@ static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, 
   int rc = 0;
   const bool ca0 = ca == 0.f;
   const int slot = (f16 ? 0 : 4) + (ca0 ? 0 : 2) + (pipe ? 0 : 1);
-#define MI_ISPF(TI, CA0, MAXIT, PIPE) rc = ispf_launch<TI, CA0, MAXIT, PIPE>(a, nblocks, slot, s, &ok)
+#define MI_ISPF(TI, CA0, MAXIT, PIPE, BPC) rc = ispf_launch<TI, CA0, MAXIT, PIPE, BPC>(a, nblocks, slot, s, &ok)
   if (f16) {
-    if (ca0) { if (pipe) MI_ISPF(half_t, true, 3, true); else MI_ISPF(half_t, true, 6, false); }
-    else     { if (pipe) MI_ISPF(half_t, false, 3, true); else MI_ISPF(half_t, false, 6, false); }
+    if (ca0) { if (pipe) MI_ISPF(half_t, true, 3, true, 2); else MI_ISPF(half_t, true, 6, false, 2); }
+    else     { if (pipe) MI_ISPF(half_t, false, 3, true, 2); else MI_ISPF(half_t, false, 6, false, 2); }
   } else {
-    if (ca0) { if (pipe) MI_ISPF(float, true, 3, true); else MI_ISPF(float, true, 6, false); }
-    else     { if (pipe) MI_ISPF(float, false, 3, true); else MI_ISPF(float, false, 6, false); }
+    if (ca0) { if (pipe) MI_ISPF(float, true, 3, true, 2); else MI_ISPF(float, true, 4, false, 2); }
+    else     { if (pipe) MI_ISPF(float, false, 3, true, 2); else MI_ISPF(float, false, 4, false, 2); }
   }
 #undef MI_ISPF
   if (rc || !ok) return rc;

@@ -25,6 +25,11 @@ def world_size(group) -> int:
     return dist.get_world_size(group) if active(group) else 1
 
 
+# Measurement hook (bench.py --workload isp-shared-stats): when a list, every RCCL all-gather is bracketed by a pair of
+# events on the stream it is enqueued on; the caller reads the pairs behind a synchronisation.  None: no events.
+collective_events = None
+
+
 def all_gather_rows(row: torch.Tensor, group) -> torch.Tensor:
     """(k,) per rank -> (world, k) on every rank; one collective."""
     if not active(group):
@@ -32,6 +37,13 @@ def all_gather_rows(row: torch.Tensor, group) -> torch.Tensor:
     world = dist.get_world_size(group)
     if row.is_cuda and dist.get_backend(group) != "gloo":
         out = torch.empty((world, row.numel()), dtype=row.dtype, device=row.device)
+        if collective_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(row.device))
+            dist.all_gather_into_tensor(out, row.contiguous(), group=group)
+            e1.record(torch.cuda.current_stream(row.device))
+            collective_events.append((e0, e1))
+            return out
         dist.all_gather_into_tensor(out, row.contiguous(), group=group)
         return out
     host = row.detach().cpu().contiguous()

@@ -111,3 +111,21 @@ def test_bench_starts_its_own_ranks_on_one_gpu():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
     assert "multi-pass" in line["config"]["chain"]
+    # the line explains itself: backend and rank count as the process group reports them, the scaling mode, per-rank times
+    assert line["backend"] == "gloo" and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["frames_per_step_all_ranks"] == 4 and line["config"]["frames_per_rank_per_step"] == 2
+    br = line["us_per_frame_by_rank"]
+    assert len(br["per_rank"]) == 2 and 0 < br["min"] <= br["max"]
+    # strong scaling: --frames is the total, split over the ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4",
+                        "--scaling", "strong", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["frames_per_rank_per_step"] == 2
+    assert line["config"]["frames_per_step_all_ranks"] == 4 and line["ranks_seen"] == 2
+    # config 5 (shared rolling statistics): the collectives' time per step is in the line (gloo: through the host, no events)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2",
+                        "--workload", "isp-shared-stats"], env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["ranks_seen"] == 2 and "collective_us_per_step" in line and "us_per_frame_by_rank" in line

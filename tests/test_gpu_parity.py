@@ -820,10 +820,7 @@ def test_isp_reinhard_in_one_launch_equals_two_passes(ti, dev, cam, shape, n, kw
     frames = [torch.from_numpy(natural_packed12(np.random.default_rng(700 + k), H, W, dark=0.03 * k)).to(dev) for k in range(n)]
 
     def run(two_pass):
-        if two_pass:
-            monkeypatch.setenv("MI_ISP_REINHARD_LAUNCHES", "2")
-        else:
-            monkeypatch.delenv("MI_ISP_REINHARD_LAUNCHES", raising=False)
+        monkeypatch.setenv("MI_ISP_REINHARD_LAUNCHES", "2" if two_pass else "1")
         isp = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.4, device=dev)
         res = []
         for step in range(2):
@@ -837,7 +834,8 @@ def test_isp_reinhard_in_one_launch_equals_two_passes(ti, dev, cam, shape, n, kw
     for step in range(2):
         assert torch.equal(one[step][3], two[step][3])
         for k in range(n):
-            assert torch.equal(one[step][1][k], two[step][1][k]), f"step {step} image {k}: in-place p differs"
+            bits = torch.int16 if cam == "Camera16" else torch.int32      # (bit patterns: p may hold NaN - black pixels)
+            assert torch.equal(one[step][1][k].view(bits), two[step][1][k].view(bits)), f"step {step} image {k}: in-place p differs"
             assert torch.equal(one[step][2][k], two[step][2][k]), f"step {step} image {k}: u8 output differs"
     if c_oracle.available():
         before, after, outs, metrics = one[1]
@@ -848,12 +846,13 @@ def test_isp_reinhard_in_one_launch_equals_two_passes(ti, dev, cam, shape, n, kw
     assert _native.lib().mi_isp_reinhard_faults(1) == 0
 
 
-def test_isp_reinhard_one_launch_timeout_is_reported(ti, dev):
+def test_isp_reinhard_one_launch_timeout_is_reported(ti, dev, monkeypatch):
     """The fused tonemap's wait for max_out with a budget of one poll: a block that looks before the others have arrived
     gives up - fault word, mailbox, TonemapTimeout at the next call - and nothing hangs; the call after that is clean."""
     from taichi_image_amd import _native
     from taichi_image_amd.camera_isp import TonemapTimeout
     L = _native.lib()
+    monkeypatch.setenv("MI_ISP_REINHARD_LAUNCHES", "1")           # (the one-launch form is opt-in: measured slower)
     H, W = 768, 1024
     frames = [torch.from_numpy(natural_packed12(np.random.default_rng(800 + k), H, W)).to(dev) for k in range(4)]
     isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.4, device=dev)
