@@ -2,6 +2,7 @@
 # Dynamic instruction mix of the whole-frame kernel (scripts/mega_check.py): VALU classes, cycles, LDS waits - separate runs.
 set -o pipefail
 TAG=${1:-pmc_mix}
+DRIVER=${2:-mega_check.py}             # round 4: "prof_batch.py 64 3" = the headline's 64-frame launches (counts are per LAUNCH)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT && mkdir -p $OUT
@@ -14,7 +15,7 @@ for set in "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ
            "SQ_INSTS_VALU_ADD_F16 SQ_INSTS_VALU_MUL_F16 SQ_INSTS_VALU_FMA_F16 SQ_INSTS_BRANCH" \
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/scripts/mega_check.py > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/scripts/$DRIVER > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
 done
 python3 - <<PY
 import csv, glob, collections
