@@ -190,12 +190,8 @@ int mi_isp_load_packed(const uint8_t* packed_dev, void* rgb_dev, int H, int W, i
 size_t mi_isp_metering_sub_bytes(int H, int W, int stride, int dtype);
 /* camera_isp.py:142-175 on n_images such buffers (the subsamples of H x W images at `stride`): same metrics as
  * mi_isp_metering on the images, bit for bit. */
-int mi_isp_metering_sub(const void* const* subs_host, int n_images, int H, int W, int stride, int dtype, int n_partials,
+int mi_isp_metering_sub(const void* const* subs_host, int n_images, int H, int W, int stride, int dtype,
                         float* state9_dev, float alpha, void* ws_dev, void* stream);
-/* n_partials: the number of pairs in each buffer's tail = mi_isp_load_packed_partials(..) of the load that filled it (the
- * waves of the load kernel that wrote the samples; 1 where a gather made them). */
-int mi_isp_load_packed_partials(int H, int W, int bits, int ids_format, int work_dtype, int Hd, int Wd, float scale,
-                                int sub_stride);
 /* does the fused load + resize (scale > 0) leave the destination image's subsample itself? */
 int mi_isp_load_packed_resized_metered_is_fused(int H, int W, int bits, int ids_format, int work_dtype, int Hd, int Wd,
                                                 float scale, int sub_stride);

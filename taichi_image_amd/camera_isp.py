@@ -66,22 +66,22 @@ def _sub_buffer(L, hd, wd, st, dt, torch_dtype, device):
     return raw, raw[:n].view(torch_dtype).view(hs, ws, 3)
 
 
-def _tag_subsample(rgb, sub, stride, raw=None, n_partials=0):
+def _tag_subsample(rgb, sub, stride, raw=None):
     """Hang the dense metering subsample the load kernel left (`rgb[::stride, ::stride]`) on the image.  The tag is valid
     while the image's version counter stands still: torch writes move it, the library's own in-place writes move it
     explicitly (_written_in_place).  A tensor without a counter (created under torch.inference_mode(), as the reference's
     bench does, bench/camera_isp.py:53) gets no tag - update_metering then gathers from the image itself."""
     v = _version_of(rgb)
     if v is not None:
-        rgb._mi_metering_sub = (sub, stride, v, raw, n_partials)
+        rgb._mi_metering_sub = (sub, stride, v, raw)
 
 
 def _valid_subsample(im, stride):
-    """(samples view, raw buffer with the bounds tail, pairs in the tail) of a still valid tag, else None."""
+    """(samples view, raw buffer with the bounds tail) of a still valid tag, else None."""
     tag = getattr(im, "_mi_metering_sub", None)
     if tag is None or tag[1] != stride or tag[2] != _version_of(im):
         return None
-    return tag[0], tag[3], tag[4]
+    return tag[0], tag[3]
 
 
 def _written_in_place(images):
@@ -296,16 +296,8 @@ def camera_isp(name: str, dtype=types.f32):
                 src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value,
                 _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, float(scale) if fused else 0.0,
                 raw.data_ptr(), st, _native.stream_ptr(self.device)))
-            _tag_subsample(rgb, sub, st, raw, self._load_partials(L, h, w, bits, ids_format, hd, wd, scale if fused else 0.0, st))
+            _tag_subsample(rgb, sub, st, raw)
             return rgb
-
-        def _load_partials(self, L, h, w, bits, ids_format, hd, wd, scale, st):
-            """Pairs of bounds the load of this configuration leaves in a subsample buffer's tail (cached per configuration)."""
-            key = (h, w, bits, bool(ids_format), hd, wd, float(scale), st)
-            cache = self.__dict__.setdefault("_partials_cache", {})
-            if key not in cache:
-                cache[key] = int(L.mi_isp_load_packed_partials(h, w, bits, int(bool(ids_format)), dtype.code, hd, wd, float(scale), st))
-            return cache[key]
 
         def _load_leaves_subsample(self, L, h, w, bits, ids_format, hd, wd, scale, st):
             """Does the load kernel of this configuration write image[::st, ::st] (and its bounds) itself?"""
@@ -366,9 +358,8 @@ def camera_isp(name: str, dtype=types.f32):
                 h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value, _native.ccm_arg(self.color_correct_matrix),
                 dtype.code, hd, wd, float(scale) if fused else 0.0, st, _native.stream_ptr(self.device)))
             if bufs is not None:
-                npart = self._load_partials(L, h, w, bits, ids_format, hd, wd, scale if fused else 0.0, st)
                 for rgb, (raw, sub) in zip(rgbs, bufs):
-                    _tag_subsample(rgb, sub, st, raw, npart)
+                    _tag_subsample(rgb, sub, st, raw)
             return rgbs
 
         def load_packed16(self, image_data):
@@ -404,7 +395,7 @@ def camera_isp(name: str, dtype=types.f32):
             subs = [_valid_subsample(im, stride) for im in images]
             raws = None
             if all(s is not None for s in subs):
-                if (all(s[1] is not None and s[2] == subs[0][2] and s[2] > 0 for s in subs) and self.process_group is None):
+                if all(s[1] is not None for s in subs) and self.process_group is None:
                     raws = [s[1] for s in subs]            # with the bounds tail: mi_isp_metering_sub
                 else:
                     images = [s[0] for s in subs]
@@ -423,7 +414,7 @@ def camera_isp(name: str, dtype=types.f32):
             if raws is not None:
                 # the dense subsamples the load kernels left, their first pass folded from the loading waves' bounds
                 metering = prev.clone()
-                _native.check(L.mi_isp_metering_sub(_native.ptr_array(raws), len(raws), H, W, stride, dtype.code, subs[0][2],
+                _native.check(L.mi_isp_metering_sub(_native.ptr_array(raws), len(raws), H, W, stride, dtype.code,
                                                     metering.data_ptr(), float(t), ws.data_ptr(), stream))
                 return metering
             if self.process_group is None:

@@ -295,25 +295,6 @@ extern "C" int mi_isp_load_packed_metered(const uint8_t* packed, void* rgb, int 
   return load_packed_impl(packed, rgb, H, W, bits, ids_format, pattern, ccm9, work_dtype, Hd, Wd, scale, sub, sub_stride, stream);
 }
 
-// How many pairs of bounds mi_isp_load_packed_metered / _batch leave in the tail of a subsample buffer for this
-// configuration (what mi_isp_metering_sub wants to know): the waves of the load kernel that writes the samples itself,
-// 1 where a gather makes them.
-extern "C" int mi_isp_load_packed_partials(int H, int W, int bits, int ids_format, int work_dtype, int Hd, int Wd, float scale,
-                                           int sub_stride) {
-  if (H <= 0 || W <= 0 || sub_stride < 1) return 0;
-  if (scale > 0.f) {
-    if (!mi_isp_load_packed_resized_metered_is_fused(H, W, bits, ids_format, work_dtype, Hd, Wd, scale, sub_stride)) return 1;
-    rstrm::RSArgs ra = {};
-    ra.s0 = scale; ra.s1 = scale;
-    rstrm::geometry(H, W, ra);
-    return ra.n_waves <= MI_SUB_PARTIALS_MAX ? ra.n_waves : 1;
-  }
-  if (!mi_isp_load_packed_metered_is_fused(H, W, bits, ids_format, work_dtype, sub_stride)) return 1;
-  strm::SArgs a = {};
-  strm::geometry(H, W, a);
-  return a.n_waves <= MI_SUB_PARTIALS_MAX ? a.n_waves : 1;
-}
-
 extern "C" int mi_isp_load_packed_scale_supported(float scale) { return rtile::scales_fit(scale, scale) ? 1 : 0; }
 
 // ---- measurement aid: HIP events around each data pass, on the stream it runs on ---------------------

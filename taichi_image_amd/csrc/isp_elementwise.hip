@@ -1201,7 +1201,6 @@ struct MeterFused {
   float alpha, n_px;
   uint32_t tag;              // phase 0; phase 1 = tag + 1
   uint32_t tail_off;         // PRE: the images are dense subsample buffers with a tail of per-wave bounds at this byte offset
-  int n_partials;            // PRE: pairs in every tail (the host knows the loaders' geometry; the tails carry it too)
   unsigned spin_limit;
   unsigned* fault;           // the workspace's fault word (mi_isp_workspace_check)
   unsigned* mailbox;         // host-mapped word of the device (mi_isp_metering_faults): seen without a synchronisation
@@ -1243,17 +1242,12 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
   const int step = a.bpi * METER_THREADS;
   if constexpr (PRE) {
     float lo = __builtin_inff(), hi = -__builtin_inff();
-    // every thread's loads are independent of each other (the pair count is a kernel argument, the pointers scalar loads):
-    // one round trip for all images.  (Reading each tail's own count first made it two dependent round trips PER IMAGE:
-    // 17.7 us for six 4K cameras, slower than the pass it replaces.)
-    const int np = a.n_partials < MI_SUB_PARTIALS_MAX ? a.n_partials : MI_SUB_PARTIALS_MAX;
     for (int im = 0; im < a.n_images; ++im) {
-      const float2* pairs = reinterpret_cast<const float2*>(static_cast<const char*>(a.imgs.p[im]) + a.tail_off + 16);
-#pragma unroll
-      for (int u = 0; u < MI_SUB_PARTIALS_MAX / METER_THREADS; ++u) {
-        const int i = u * METER_THREADS + threadIdx.x;
-        if (i < np) { const float2 q = pairs[i]; lo = fminf(lo, q.x); hi = fmaxf(hi, q.y); }
-      }
+      const float* tail = reinterpret_cast<const float*>(static_cast<const char*>(a.imgs.p[im]) + a.tail_off);
+      int np = reinterpret_cast<const int*>(tail)[0];
+      np = np < 0 ? 0 : (np > MI_SUB_PARTIALS_MAX ? MI_SUB_PARTIALS_MAX : np);
+      const float2* pairs = reinterpret_cast<const float2*>(tail + 4);
+      for (int i = threadIdx.x; i < np; i += METER_THREADS) { const float2 q = pairs[i]; lo = fminf(lo, q.x); hi = fmaxf(hi, q.y); }
     }
     lo = wave_min(lo); hi = wave_max(hi);
     if (lane == 0) { red[wave][0] = lo; red[wave][1] = hi; }
@@ -2009,8 +2003,7 @@ static std::atomic<uint32_t> g_meter_launches{0};
 // Its launches take part in the one order of the library's resident grids (ew::resident_order, isp_elementwise.h).
 static std::atomic<unsigned> g_meter_poll_limit{0};          // 0 = default; tests: mi_isp_metering_set_poll_limit
 static int metering_fused(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
-                          float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done, uint32_t tail_off = 0,
-                          int n_partials = 0) {
+                          float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done, uint32_t tail_off = 0) {
   *done = false;
   const char* env = getenv("MI_ISP_METERING_LAUNCHES");       // (read per call: a test switches it)
   if ((env && atoi(env) == 4) || n_images > 64 || n_images > METER_MAX_BLOCKS) return 0;
@@ -2032,7 +2025,7 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
   a.H = H; a.W = W; a.stride = stride; a.bpi = bpi; a.n_images = n_images;
   a.fp = fp; a.rec0 = partials; a.rec1 = partials + cap;       // partial rows 0 and 1..3 (cap >= 1024 floats each)
   a.state9 = state9; a.alpha = alpha; a.n_px = (float)((int64_t)n_images * hs * wss);
-  a.tail_off = tail_off; a.n_partials = n_partials;
+  a.tail_off = tail_off;
   // a quiet NaN with a payload, two per launch (0x7FC00001 ...): see the kernel's head
   const uint32_t k = g_meter_launches.fetch_add(1, std::memory_order_relaxed);
   a.tag = 0x7FC00001u + 2u * (k % 0x1FFFFFu);
@@ -2138,11 +2131,9 @@ extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, i
 // the buffers' tails instead of read from the samples.  Same samples, same blends; the raw bounds are the exact min / max
 // either way, so the metrics are those of mi_isp_metering on the images bit for bit.  Falls back to mi_isp_metering on the
 // samples (stride 1) where the one-launch kernel does not apply.
-extern "C" int mi_isp_metering_sub(const void* const* subs, int n_images, int H, int W, int stride, int dtype, int n_partials,
-                                   float* state9, float alpha, void* ws, void* stream) {
+extern "C" int mi_isp_metering_sub(const void* const* subs, int n_images, int H, int W, int stride, int dtype, float* state9,
+                                   float alpha, void* ws, void* stream) {
   MI_REQUIRE(stride >= 1 && H > 0 && W > 0, "metering_sub: bad shape");
-  MI_REQUIRE(n_partials >= 1 && n_partials <= MI_SUB_PARTIALS_MAX, "metering_sub: %d pairs of bounds per buffer (1..%d)", n_partials,
-             MI_SUB_PARTIALS_MAX);
   const int hs = (H + stride - 1) / stride, wss = (W + stride - 1) / stride;
   if (int rc = metering_check(subs, n_images, hs, wss, 1, dtype, ws)) return rc;
   MI_REQUIRE(state9, "metering_sub: null state");
@@ -2151,8 +2142,7 @@ extern "C" int mi_isp_metering_sub(const void* const* subs, int n_images, int H,
   const int cap = mi_partial_cap(hs, wss);
   bool done = false;
   const uint32_t tail_off = (uint32_t)mi_sub_tail_offset(H, W, stride, mi_dtype_size(dtype));
-  if (int rc = metering_fused(subs, n_images, hs, wss, 1, dtype, state9, alpha, fp, fp + FP_COUNT, cap, s, &done, tail_off, n_partials))
-    return rc;
+  if (int rc = metering_fused(subs, n_images, hs, wss, 1, dtype, state9, alpha, fp, fp + FP_COUNT, cap, s, &done, tail_off)) return rc;
   if (done) return 0;
   return mi_isp_metering(subs, n_images, hs, wss, 1, dtype, state9, alpha, ws, stream);
 }

@@ -735,21 +735,14 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
       if constexpr (EPI == S_STORE) {
         if (sub_p && (row & 7) == 0 && col_ok) {         // (row: wave-uniform)
           E* sp = static_cast<E*>(sub_p) + ((size_t)(row >> 3) * a.sub_w + (size_t)(c0 >> 3)) * 3;
-          float s3[3];                                    // the stored - clamped, rounded - values of the sample
           if constexpr (sizeof(E) == 2) {
             uint16_t* s16 = reinterpret_cast<uint16_t*>(sp);
             s16[0] = (uint16_t)(pk[0] & 0xFFFFu); s16[1] = (uint16_t)(pk[0] >> 16); s16[2] = (uint16_t)(pk[1] & 0xFFFFu);
-            half_t h[4];
-            __builtin_memcpy(h, pk, 8);                   // (t[] is not unpacked in the storing kernel)
-            s3[0] = (float)h[0]; s3[1] = (float)h[1]; s3[2] = (float)h[2];
           } else {
             sp[0] = (E)t[0]; sp[1] = (E)t[1]; sp[2] = (E)t[2];
-            s3[0] = t[0]; s3[1] = t[1]; s3[2] = t[2];
           }
-#ifndef MI_NO_SUB_BOUNDS
-          smin = fminf(smin, fminf(s3[0], fminf(s3[1], s3[2])));
-          smax = fmaxf(smax, fmaxf(s3[0], fmaxf(s3[1], s3[2])));
-#endif
+          smin = fminf(smin, fminf(t[0], fminf(t[1], t[2])));   // (t: the stored - clamped, rounded - values)
+          smax = fmaxf(smax, fmaxf(t[0], fmaxf(t[1], t[2])));
         }
       }
       if constexpr (EPI == S_STORE || EPI == S_STORE_BOUNDS) {

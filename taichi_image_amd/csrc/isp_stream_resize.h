@@ -249,7 +249,6 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
       const int cl = gbase + 4 * lane;
       // the metering sample of this row: destination pixels (r % 8 == 0, c % 8 == 0) - a lane's first pixel when its four
       // start at a multiple of 8
-#ifndef MI_NO_SUB_BOUNDS
       if (sub_p && (r & 7) == 0 && (cl & 7) == 0 && tap[0].valid) {          // (r: wave-uniform)
         half_t* sp = sub_p + ((size_t)(r >> 3) * a.sub_w + (size_t)(cl >> 3)) * 3;
         sp[0] = oh[0]; sp[1] = oh[1]; sp[2] = oh[2];
@@ -257,7 +256,6 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
         smin = fminf(smin, fminf(s0, fminf(s1, s2)));
         smax = fmaxf(smax, fmaxf(s0, fmaxf(s1, s2)));
       }
-#endif
       const bool all4 = vec_rows && tap[0].valid && tap[3].valid;
       const uint32_t base = ((uint32_t)r * (uint32_t)a.Wd + (uint32_t)cl) * 6u;
       typedef uint32_t u2 __attribute__((ext_vector_type(2)));
