@@ -181,20 +181,7 @@ int mi_isp_load_packed(const uint8_t* packed_dev, void* rgb_dev, int H, int W, i
  * (ceil(Hd / sub_stride), ceil(Wd / sub_stride), 3) image of work_dtype - what ISP.update_metering reads of every image
  * (camera_isp.py:168-170).  mi_isp_metering(..) on these buffers with stride 1 gives the bits of mi_isp_metering on the
  * images with stride sub_stride (same samples, same order) without the strided gather over the full-size images.  With
- * sub_stride 8 the subsample is written by the load kernel itself (full size: strm::stream_kernel; round 4: the fused load +
- * resize too); otherwise by a small gather behind it.
- * Round 4: sub_dev is mi_isp_metering_sub_bytes(Hd, Wd, sub_stride, work_dtype) bytes - the samples, padding to 16 bytes,
- * and a TAIL: int32 n, three words of padding, n pairs {min, max} (fp32), the bounds of the samples each wave of the load
- * kernel wrote (one pair over all samples where a gather made them).  mi_isp_metering_sub(..) folds those pairs instead of
- * running the first pass of camera_isp.py:152-153 over the samples (and the grid barrier behind it). */
-size_t mi_isp_metering_sub_bytes(int H, int W, int stride, int dtype);
-/* camera_isp.py:142-175 on n_images such buffers (the subsamples of H x W images at `stride`): same metrics as
- * mi_isp_metering on the images, bit for bit. */
-int mi_isp_metering_sub(const void* const* subs_host, int n_images, int H, int W, int stride, int dtype,
-                        float* state9_dev, float alpha, void* ws_dev, void* stream);
-/* does the fused load + resize (scale > 0) leave the destination image's subsample itself? */
-int mi_isp_load_packed_resized_metered_is_fused(int H, int W, int bits, int ids_format, int work_dtype, int Hd, int Wd,
-                                                float scale, int sub_stride);
+ * sub_stride 8 and no resize the subsample is written by the load kernel itself; otherwise by a small gather behind it. */
 int mi_isp_load_packed_metered(const uint8_t* packed_dev, void* rgb_dev, int H, int W, int bits,
                                int ids_format, int pattern, const float* ccm9_host, int work_dtype,
                                int Hd, int Wd, float scale, void* sub_dev, int sub_stride, void* stream);

@@ -55,9 +55,6 @@ SIGNATURES = {
     "mi_isp_load_packed_batch": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, c_int, c_int,
                                          POINTER(c_float), c_int, c_int, c_int, c_float, c_int, _P]),
     "mi_isp_load_packed_metered_is_fused": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "mi_isp_load_packed_resized_metered_is_fused": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
-    "mi_isp_metering_sub_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "mi_isp_metering_sub": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P]),
     "mi_isp_load_packed_scale_supported": (c_int, [c_float]),
     "mi_isp_pipeline12_reinhard": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int,
                                            c_float, c_float, c_float, c_float, _P, _P]),

@@ -57,31 +57,21 @@ def _version_of(t):
         return None
 
 
-def _sub_buffer(L, hd, wd, st, dt, torch_dtype, device):
-    """A dense metering subsample buffer (include/mi_isp.h: mi_isp_load_packed_metered): the raw bytes the C side fills
-    - samples, then the tail with the loading waves' bounds - and the (hs, ws, 3) view of the samples."""
-    raw = torch.empty(int(L.mi_isp_metering_sub_bytes(hd, wd, st, dt.code)), dtype=torch.uint8, device=device)
-    hs, ws = (hd + st - 1) // st, (wd + st - 1) // st
-    n = hs * ws * 3 * torch.empty((), dtype=torch_dtype).element_size()
-    return raw, raw[:n].view(torch_dtype).view(hs, ws, 3)
-
-
-def _tag_subsample(rgb, sub, stride, raw=None):
+def _tag_subsample(rgb, sub, stride):
     """Hang the dense metering subsample the load kernel left (`rgb[::stride, ::stride]`) on the image.  The tag is valid
     while the image's version counter stands still: torch writes move it, the library's own in-place writes move it
     explicitly (_written_in_place).  A tensor without a counter (created under torch.inference_mode(), as the reference's
     bench does, bench/camera_isp.py:53) gets no tag - update_metering then gathers from the image itself."""
     v = _version_of(rgb)
     if v is not None:
-        rgb._mi_metering_sub = (sub, stride, v, raw)
+        rgb._mi_metering_sub = (sub, stride, v)
 
 
 def _valid_subsample(im, stride):
-    """(samples view, raw buffer with the bounds tail) of a still valid tag, else None."""
     tag = getattr(im, "_mi_metering_sub", None)
     if tag is None or tag[1] != stride or tag[2] != _version_of(im):
         return None
-    return tag[0], tag[3]
+    return tag[0]
 
 
 def _written_in_place(images):
@@ -282,29 +272,21 @@ def camera_isp(name: str, dtype=types.f32):
                     _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, 0.0, _native.stream_ptr(self.device)))
                 return self.resize_image(rgb)
             st = self.metering_stride
-            if not self._load_leaves_subsample(L, h, w, bits, ids_format, hd, wd, scale if fused else 0.0, st):
+            if fused or not L.mi_isp_load_packed_metered_is_fused(h, w, bits, int(bool(ids_format)), dtype.code, st):
                 _native.check(L.mi_isp_load_packed(
                     src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value,
                     _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, float(scale) if fused else 0.0,
                     _native.stream_ptr(self.device)))
                 return rgb
-            # the image and, on the way, the stride-subsampled copy update_metering will ask for (camera_isp.py:168-170) with
-            # the bounds of its samples: the load kernel holds those pixels anyway, the strided gather over six 4K images
-            # costs 25 us per call (round 4: the fused load + resize leaves them too, and the bounds save the first pass)
-            raw, sub = _sub_buffer(L, hd, wd, st, dtype, torch_dtype, self.device)
+            # the image and, on the way, the stride-subsampled copy update_metering will ask for (camera_isp.py:168-170):
+            # the load kernel holds those pixels anyway, the strided gather over six 4K images costs 25 us per call
+            sub = torch.empty(((hd + st - 1) // st, (wd + st - 1) // st, 3), dtype=torch_dtype, device=self.device)
             _native.check(L.mi_isp_load_packed_metered(
                 src.data_ptr(), rgb.data_ptr(), h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value,
-                _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, float(scale) if fused else 0.0,
-                raw.data_ptr(), st, _native.stream_ptr(self.device)))
-            _tag_subsample(rgb, sub, st, raw)
+                _native.ccm_arg(self.color_correct_matrix), dtype.code, hd, wd, 0.0,
+                sub.data_ptr(), st, _native.stream_ptr(self.device)))
+            _tag_subsample(rgb, sub, st)
             return rgb
-
-        def _load_leaves_subsample(self, L, h, w, bits, ids_format, hd, wd, scale, st):
-            """Does the load kernel of this configuration write image[::st, ::st] (and its bounds) itself?"""
-            if scale > 0:
-                return bool(L.mi_isp_load_packed_resized_metered_is_fused(h, w, bits, int(bool(ids_format)), dtype.code, hd, wd,
-                                                                           float(scale), st))
-            return bool(L.mi_isp_load_packed_metered_is_fused(h, w, bits, int(bool(ids_format)), dtype.code, st))
 
         def load_packed12(self, image_data, ids_format=False):
             """camera_isp.py:333-340: unpack + demosaic (+ccm) fused in one pass over the packed frame."""
@@ -350,16 +332,16 @@ def camera_isp(name: str, dtype=types.f32):
             srcs = [d.to(self.device).contiguous() for d in images_data]
             rgbs = [torch.empty((hd, wd, 3), dtype=torch_dtype, device=self.device) for _ in srcs]
             st = self.metering_stride
-            metered = self._load_leaves_subsample(L, h, w, bits, ids_format, hd, wd, scale if fused else 0.0, st)
-            bufs = [_sub_buffer(L, hd, wd, st, dtype, torch_dtype, self.device) for _ in srcs] if metered else None
-            subs = None if bufs is None else [b[1] for b in bufs]
+            metered = not fused and bool(L.mi_isp_load_packed_metered_is_fused(h, w, bits, int(bool(ids_format)), dtype.code, st))
+            subs = [torch.empty(((hd + st - 1) // st, (wd + st - 1) // st, 3), dtype=torch_dtype, device=self.device)
+                    for _ in srcs] if metered else None
             _native.check(L.mi_isp_load_packed_batch(
-                _native.ptr_array(srcs), _native.ptr_array(rgbs), None if bufs is None else _native.ptr_array([b[0] for b in bufs]), len(srcs),
+                _native.ptr_array(srcs), _native.ptr_array(rgbs), None if subs is None else _native.ptr_array(subs), len(srcs),
                 h, w, bits, int(bool(ids_format)), self._demosaic_pattern.value, _native.ccm_arg(self.color_correct_matrix),
                 dtype.code, hd, wd, float(scale) if fused else 0.0, st, _native.stream_ptr(self.device)))
-            if bufs is not None:
-                for rgb, (raw, sub) in zip(rgbs, bufs):
-                    _tag_subsample(rgb, sub, st, raw)
+            if subs is not None:
+                for rgb, sub in zip(rgbs, subs):
+                    _tag_subsample(rgb, sub, st)
             return rgbs
 
         def load_packed16(self, image_data):
@@ -393,14 +375,10 @@ def camera_isp(name: str, dtype=types.f32):
             # images that came out of load_packed12 / 16 carry their subsample: the same samples in the same order from a
             # dense buffer (stride 1) - identical results, no strided gather over the full-size images
             subs = [_valid_subsample(im, stride) for im in images]
-            raws = None
             if all(s is not None for s in subs):
-                if all(s[1] is not None for s in subs) and self.process_group is None:
-                    raws = [s[1] for s in subs]            # with the bounds tail: mi_isp_metering_sub
-                else:
-                    images = [s[0] for s in subs]
-                    H, W = images[0].shape[:2]
-                    stride = 1
+                images = subs
+                H, W = images[0].shape[:2]
+                stride = 1
             ptrs = _native.ptr_array(images)
             L = _native.lib()
             stream = _native.stream_ptr(self.device)
@@ -411,12 +389,6 @@ def camera_isp(name: str, dtype=types.f32):
                 if L.mi_isp_reinhard_faults(1):
                     raise TonemapTimeout("an earlier tonemap_reinhard on this device timed out waiting for an image's "
                                          "max_out: the outputs of that call are invalid")
-            if raws is not None:
-                # the dense subsamples the load kernels left, their first pass folded from the loading waves' bounds
-                metering = prev.clone()
-                _native.check(L.mi_isp_metering_sub(_native.ptr_array(raws), len(raws), H, W, stride, dtype.code,
-                                                    metering.data_ptr(), float(t), ws.data_ptr(), stream))
-                return metering
             if self.process_group is None:
                 metering = prev.clone()
                 _native.check(L.mi_isp_metering(ptrs, len(images), H, W, stride, dtype.code,

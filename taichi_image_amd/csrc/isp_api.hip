@@ -126,12 +126,6 @@ static bool use_stream(const tile::Params& p, int work_dtype, const void* out, i
          (int64_t)p.H * p.W * 3 * (int64_t)mi_dtype_size(out_dtype) < (int64_t)strm::INVALID_OFF;
 }
 
-// a loader whose kernel does not leave the subsample: a gather behind it, then the tail's single pair of bounds
-static int sub_fallback(const void* rgb, void* sub, int H, int W, int stride, int dtype, void* stream) {
-  if (int rc = ew::subsample(rgb, sub, H, W, stride, dtype, (hipStream_t)stream)) return rc;
-  return ew::sub_bounds(sub, H, W, stride, dtype, (hipStream_t)stream);
-}
-
 static int load_packed_impl(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,
                             int pattern, const float* ccm9, int work_dtype, int Hd, int Wd, float scale,
                             void* sub, int sub_stride, void* stream) {
@@ -150,15 +144,8 @@ static int load_packed_impl(const uint8_t* packed, void* rgb, int H, int W, int 
 #ifdef MI_STREAM_STAMPS
       ra.t.partials = stamp_buffer(); ra.t.part_stride = 0;      // this entry point has no workspace: a buffer of the build
 #endif
-      if (sub && sub_stride == 8) {                            // the metering subsample and its bounds on the way
-        ra.sub = sub; ra.sub_w = (Wd + 7) / 8;
-        ra.sub_tail_off = (uint32_t)mi_sub_tail_offset(Hd, Wd, 8, mi_dtype_size(work_dtype));
-      }
-      const bool tail_fits = ra.n_waves <= MI_SUB_PARTIALS_MAX;
-      if (!tail_fits) ra.sub_tail_off = 0;
       if (int rc = rstrm::launch(ra, pattern, (hipStream_t)stream)) return rc;
-      if (sub && sub_stride != 8) return sub_fallback(rgb, sub, Hd, Wd, sub_stride, work_dtype, stream);
-      if (sub && !tail_fits) return ew::sub_bounds(sub, Hd, Wd, 8, work_dtype, (hipStream_t)stream);
+      if (sub) return ew::subsample(rgb, sub, Hd, Wd, sub_stride, work_dtype, (hipStream_t)stream);
       return 0;
     }
     MI_REQUIRE(rtile::scales_fit(scale, scale), "load_packed: scale %g is outside the fused kernel's range "
@@ -166,7 +153,7 @@ static int load_packed_impl(const uint8_t* packed, void* rgb, int H, int W, int 
     rtile::RParams rp = {};
     rp.t = p; rp.Hd = Hd; rp.Wd = Wd; rp.s0 = scale; rp.s1 = scale;
     if (int rc = rtile::launch(rp, work_dtype, pattern, (hipStream_t)stream)) return rc;
-    if (sub) return sub_fallback(rgb, sub, Hd, Wd, sub_stride, work_dtype, stream);
+    if (sub) return ew::subsample(rgb, sub, Hd, Wd, sub_stride, work_dtype, (hipStream_t)stream);
     return 0;
   }
   MI_REQUIRE(Hd == H && Wd == W, "load_packed: output shape must equal the frame when scale <= 0");
@@ -175,19 +162,13 @@ static int load_packed_impl(const uint8_t* packed, void* rgb, int H, int W, int 
     strm::SArgs a = {};
     a.t = p;
     strm::geometry(H, W, a);
-    if (sub && sub_stride == 8) {                              // the metering subsample and its bounds on the way
-      a.sub = sub; a.sub_w = (W + 7) / 8;
-      a.sub_tail_off = (uint32_t)mi_sub_tail_offset(H, W, 8, mi_dtype_size(work_dtype));
-    }
-    const bool tail_fits = a.n_waves <= MI_SUB_PARTIALS_MAX;
-    if (!tail_fits) a.sub_tail_off = 0;
+    if (sub && sub_stride == 8) { a.sub = sub; a.sub_w = (W + 7) / 8; }   // the metering subsample on the way
     if (int rc = strm::launch(a, work_dtype, pattern, strm::S_STORE, (hipStream_t)stream)) return rc;
-    if (sub && sub_stride != 8) return sub_fallback(rgb, sub, H, W, sub_stride, work_dtype, stream);
-    if (sub && !tail_fits) return ew::sub_bounds(sub, H, W, 8, work_dtype, (hipStream_t)stream);
+    if (sub && sub_stride != 8) return ew::subsample(rgb, sub, H, W, sub_stride, work_dtype, (hipStream_t)stream);
     return 0;
   }
   if (int rc = tile::launch(p, work_dtype, pattern, tile::EPI_STORE, (hipStream_t)stream)) return rc;
-  if (sub) return sub_fallback(rgb, sub, H, W, sub_stride, work_dtype, stream);
+  if (sub) return ew::subsample(rgb, sub, H, W, sub_stride, work_dtype, (hipStream_t)stream);
   return 0;
 }
 
@@ -239,33 +220,21 @@ extern "C" int mi_isp_load_packed_batch(const uint8_t* const* packed, void* cons
       ra.t = p0; ra.Hd = Hd; ra.Wd = Wd; ra.s0 = scale; ra.s1 = scale;
       rstrm::geometry(H, W, ra);
       ra.n_batch = m;
-      const bool sub8 = subs && sub_stride == 8;
-      for (int i = 0; i < m; ++i) { ra.srcs[i] = packed[i0 + i]; ra.dsts[i] = rgb[i0 + i]; ra.subs[i] = sub8 ? subs[i0 + i] : nullptr; }
-      if (sub8) { ra.sub_w = (Wd + 7) / 8; ra.sub_tail_off = (uint32_t)mi_sub_tail_offset(Hd, Wd, 8, mi_dtype_size(work_dtype)); }
+      for (int i = 0; i < m; ++i) { ra.srcs[i] = packed[i0 + i]; ra.dsts[i] = rgb[i0 + i]; }
 #ifdef MI_STREAM_STAMPS
       ra.t.partials = stamp_buffer(); ra.t.part_stride = 0;
 #endif
-      const bool tail_fits = ra.n_waves <= MI_SUB_PARTIALS_MAX;
-      if (!tail_fits) ra.sub_tail_off = 0;
       if (int rc = rstrm::launch(ra, pattern, (hipStream_t)stream)) return rc;
-      if (subs && !sub8)
+      if (subs)
         for (int i = 0; i < m; ++i)
-          if (int rc = sub_fallback(rgb[i0 + i], subs[i0 + i], Hd, Wd, sub_stride, work_dtype, stream)) return rc;
-      if (sub8 && !tail_fits)
-        for (int i = 0; i < m; ++i)
-          if (int rc = ew::sub_bounds(subs[i0 + i], Hd, Wd, 8, work_dtype, (hipStream_t)stream)) return rc;
+          if (int rc = ew::subsample(rgb[i0 + i], subs[i0 + i], Hd, Wd, sub_stride, work_dtype, (hipStream_t)stream)) return rc;
     } else {
       strm::SArgs a = {};
       a.t = p0;
       strm::geometry(H, W, a);
       a.n_batch = m; a.sub_w = (W + 7) / 8;
-      const bool tail_fits = a.n_waves <= MI_SUB_PARTIALS_MAX;
-      if (subs && tail_fits) a.sub_tail_off = (uint32_t)mi_sub_tail_offset(H, W, 8, mi_dtype_size(work_dtype));
       for (int i = 0; i < m; ++i) { a.srcs[i] = packed[i0 + i]; a.dsts[i] = rgb[i0 + i]; a.subs[i] = subs ? subs[i0 + i] : nullptr; }
       if (int rc = strm::launch(a, work_dtype, pattern, strm::S_STORE, (hipStream_t)stream)) return rc;
-      if (subs && !tail_fits)
-        for (int i = 0; i < m; ++i)
-          if (int rc = ew::sub_bounds(subs[i0 + i], H, W, 8, work_dtype, (hipStream_t)stream)) return rc;
     }
   }
   return 0;
@@ -276,16 +245,6 @@ extern "C" int mi_isp_load_packed_metered_is_fused(int H, int W, int bits, int i
   tile::Params p = {};
   p.H = H; p.W = W; p.src_kind = tile::SRC_PACKED12; p.src_fast = ((int64_t)W * 3 / 2) % 4 == 0; p.in_scale = 1.f;
   return strm::supported(p, work_dtype) && (int64_t)H * W * 3 * (int64_t)mi_dtype_size(work_dtype) < (int64_t)strm::INVALID_OFF ? 1 : 0;
-}
-// the same question for the fused load + resize (scale > 0: rstrm::resize_kernel, f16): does the load kernel itself leave
-// the destination image's stride-8 subsample (and its bounds)?
-extern "C" int mi_isp_load_packed_resized_metered_is_fused(int H, int W, int bits, int ids_format, int work_dtype, int Hd, int Wd,
-                                                           float scale, int sub_stride) {
-  if (bits != 12 || ids_format || sub_stride != 8 || H < 2 || W < 8 || Hd <= 0 || Wd <= 0 || !(scale > 0.f)) return 0;
-  tile::Params p = {};
-  p.H = H; p.W = W; p.src_kind = tile::SRC_PACKED12; p.src_fast = ((int64_t)W * 3 / 2) % 4 == 0; p.in_scale = 1.f;
-  static const uint64_t aligned = 0;                          // (alignment of the output is the caller's: torch allocations are)
-  return strm::supported(p, work_dtype) && rstrm::supported(p, work_dtype, &aligned, Hd, Wd, scale, scale) ? 1 : 0;
 }
 
 extern "C" int mi_isp_load_packed_metered(const uint8_t* packed, void* rgb, int H, int W, int bits, int ids_format,

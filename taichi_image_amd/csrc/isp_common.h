@@ -234,20 +234,6 @@ enum {
   FP_MAXOUT = 18,                                   // ISP reinhard: max(1e-6, max p)
   FP_COUNT = 64
 };
-// The dense metering subsample a load kernel leaves (mi_isp_load_packed_metered; camera_isp.py:168-170: image[::s, ::s]):
-//   [ceil(H / s) * ceil(W / s) * 3 elements of the work dtype] [padding to 16 bytes]
-//   TAIL: int32 n_partials, 3 words of padding, then n_partials <= MI_SUB_PARTIALS_MAX pairs {min, max} (fp32) - the bounds
-//   of the samples each wave of the load kernel wrote (round 4: update_metering's first pass and its grid barrier
-//   become a fold of these pairs).
-constexpr int MI_SUB_PARTIALS_MAX = 4096;
-__host__ __device__ static inline size_t mi_sub_tail_offset(int H, int W, int stride, size_t elem) {
-  const size_t hs = (size_t)((H + stride - 1) / stride), ws = (size_t)((W + stride - 1) / stride);
-  return (hs * ws * 3 * elem + 15) & ~(size_t)15;
-}
-__host__ __device__ static inline size_t mi_sub_bytes(int H, int W, int stride, size_t elem) {
-  return mi_sub_tail_offset(H, W, stride, elem) + 16 + (size_t)MI_SUB_PARTIALS_MAX * 8;
-}
-
 static inline int mi_partial_cap(int H, int W) {
   // enough blocks for the tile kernels (128x32 px tiles) and the elementwise reductions
   long tiles = (long)((W + 127) / 128) * ((H + 31) / 32);

@@ -49,10 +49,6 @@ int resident_mailbox_locked(int dev);                       // allocates the dev
 int resident_enter_locked(int dev, hipStream_t s);          // mailbox + wait for the previous resident-grid launch
 int resident_leave_locked(int dev, hipStream_t s);          // record the event behind the launch just made
 
-// the tail of a dense subsample (isp_common.h: mi_sub_tail_offset) as ONE pair {min, max} over its samples: for the loaders
-// whose kernel leaves no per-wave bounds
-int sub_bounds(void* sub, int H, int W, int stride, int dtype, hipStream_t s);
-
 // ISP reinhard scalars from state9 -> FrameParams (camera_isp.py:186-195)
 int isp_reinhard_prep(const float* state9, float* fp, float intensity, float ca, hipStream_t s);
 

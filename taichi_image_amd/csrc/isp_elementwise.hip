@@ -1200,16 +1200,12 @@ struct MeterFused {
   float* state9;
   float alpha, n_px;
   uint32_t tag;              // phase 0; phase 1 = tag + 1
-  uint32_t tail_off;         // PRE: the images are dense subsample buffers with a tail of per-wave bounds at this byte offset
   unsigned spin_limit;
   unsigned* fault;           // the workspace's fault word (mi_isp_workspace_check)
   unsigned* mailbox;         // host-mapped word of the device (mi_isp_metering_faults): seen without a synchronisation
 };
 
-// PRE (round 4): the images are the dense subsamples the load kernels left, each with the bounds of every loading wave's
-// samples in its tail (isp_common.h) - pass 1 and its grid barrier become a fold of those pairs, the same in every block
-// (index order within a thread, the fixed reduction trees above that): camera_isp.py:152-153 without touching a sample.
-template <class T, bool PRE>
+template <class T>
 __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const MeterFused a) {
 #pragma clang fp contract(fast)
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -1239,32 +1235,10 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
 #define MI_METER_STAMP(i) do { } while (0)
 #endif
   MI_METER_STAMP(0);
-  const int step = a.bpi * METER_THREADS;
-  if constexpr (PRE) {
-    float lo = __builtin_inff(), hi = -__builtin_inff();
-    for (int im = 0; im < a.n_images; ++im) {
-      const float* tail = reinterpret_cast<const float*>(static_cast<const char*>(a.imgs.p[im]) + a.tail_off);
-      int np = reinterpret_cast<const int*>(tail)[0];
-      np = np < 0 ? 0 : (np > MI_SUB_PARTIALS_MAX ? MI_SUB_PARTIALS_MAX : np);
-      const float2* pairs = reinterpret_cast<const float2*>(tail + 4);
-      for (int i = threadIdx.x; i < np; i += METER_THREADS) { const float2 q = pairs[i]; lo = fminf(lo, q.x); hi = fmaxf(hi, q.y); }
-    }
-    lo = wave_min(lo); hi = wave_max(hi);
-    if (lane == 0) { red[wave][0] = lo; red[wave][1] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      lo = red[0][0]; hi = red[0][1];
-      for (int w = 1; w < METER_THREADS / 64; ++w) { lo = fminf(lo, red[w][0]); hi = fmaxf(hi, red[w][1]); }
-      // camera_isp.py:156-157: b = lerp(alpha, new, prev)  (ew::FIN_ISP_BOUNDS)
-      sh_b[0] = lo + a.alpha * (a.state9[0] - lo);
-      sh_b[1] = hi + a.alpha * (a.state9[1] - hi);
-      if (block == 0) { a.fp[FP_LO] = sh_b[0]; a.fp[FP_HI] = sh_b[1]; }
-    }
-    __syncthreads();
-  } else {
   // ---- pass 1: bounds of the samples (camera_isp.py:152-153) ----
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
   // (the gather is bound by latency: four independent samples in flight per thread)
+  const int step = a.bpi * METER_THREADS;
   for (int i0 = part * METER_THREADS + threadIdx.x; i0 < n; i0 += 4 * step) {
     float x[4][3];
 #pragma unroll
@@ -1324,7 +1298,6 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
     }
   }
   __syncthreads();
-  }
   MI_METER_STAMP(2);
   // ---- pass 2: statistics of the samples normalised by the blended bounds (camera_isp.py:117-128) ----
   const float bmin = sh_b[0], dinv = 1.0f / (sh_b[1] - sh_b[0] + 1e-6f);   // camera_isp.py:119
@@ -1593,34 +1566,7 @@ static int launch_pass(int mode, int in_dtype, int out_dtype, const PassArgs& a,
 // forward: defined with the C ABI below
 static bool vec_ok(const void* p, int dtype);
 
-// The tail of a dense subsample buffer (isp_common.h: mi_sub_tail_offset) for the loaders that have no wave bounds of
-// their own: ONE pair {min, max} over all samples, one block.
-template <class T>
-__global__ __launch_bounds__(1024) void sub_bounds_kernel(const T* __restrict__ sub, int n_values, float* __restrict__ tail) {
-  __shared__ float red[16][2];
-  float lo = __builtin_inff(), hi = -__builtin_inff();
-  for (int i = threadIdx.x; i < n_values; i += 1024) { const float x = (float)sub[i]; lo = fminf(lo, x); hi = fmaxf(hi, x); }
-  lo = wave_min(lo); hi = wave_max(hi);
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) { lo = fminf(lo, red[w][0]); hi = fmaxf(hi, red[w][1]); }
-    reinterpret_cast<int*>(tail)[0] = 1;
-    tail[4] = lo; tail[5] = hi;
-  }
-}
-
 namespace ew {
-int sub_bounds(void* sub, int H, int W, int stride, int dtype, hipStream_t s) {
-  const int hs = (H + stride - 1) / stride, ws = (W + stride - 1) / stride;
-  return dispatch_dtype(dtype, [&](auto tag) {
-    using T = decltype(tag);
-    float* tail = reinterpret_cast<float*>(static_cast<char*>(sub) + mi_sub_tail_offset(H, W, stride, sizeof(T)));
-    hipLaunchKernelGGL((sub_bounds_kernel<T>), dim3(1), dim3(1024), 0, s, static_cast<const T*>(sub), hs * ws * 3, tail);
-    MI_LAUNCH_CHECK();
-    return 0;
-  });
-}
 int subsample(const void* img, void* sub, int H, int W, int stride, int dtype, hipStream_t s) {
   const int hs = (H + stride - 1) / stride, ws = (W + stride - 1) / stride;
   int blocks = (hs * ws + EW_THREADS - 1) / EW_THREADS;
@@ -2003,7 +1949,7 @@ static std::atomic<uint32_t> g_meter_launches{0};
 // Its launches take part in the one order of the library's resident grids (ew::resident_order, isp_elementwise.h).
 static std::atomic<unsigned> g_meter_poll_limit{0};          // 0 = default; tests: mi_isp_metering_set_poll_limit
 static int metering_fused(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
-                          float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done, uint32_t tail_off = 0) {
+                          float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done) {
   *done = false;
   const char* env = getenv("MI_ISP_METERING_LAUNCHES");       // (read per call: a test switches it)
   if ((env && atoi(env) == 4) || n_images > 64 || n_images > METER_MAX_BLOCKS) return 0;
@@ -2025,7 +1971,6 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
   a.H = H; a.W = W; a.stride = stride; a.bpi = bpi; a.n_images = n_images;
   a.fp = fp; a.rec0 = partials; a.rec1 = partials + cap;       // partial rows 0 and 1..3 (cap >= 1024 floats each)
   a.state9 = state9; a.alpha = alpha; a.n_px = (float)((int64_t)n_images * hs * wss);
-  a.tail_off = tail_off;
   // a quiet NaN with a payload, two per launch (0x7FC00001 ...): see the kernel's head
   const uint32_t k = g_meter_launches.fetch_add(1, std::memory_order_relaxed);
   a.tag = 0x7FC00001u + 2u * (k % 0x1FFFFFu);
@@ -2038,8 +1983,7 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
   a.mailbox = ord.mailbox_dev[dev] + ew::MAILBOX_METERING;
   const int rc = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
-    if (tail_off) hipLaunchKernelGGL((metering_fused_kernel<T, true>), dim3(bpi, n_images), dim3(METER_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((metering_fused_kernel<T, false>), dim3(bpi, n_images), dim3(METER_THREADS), 0, s, a);
+    hipLaunchKernelGGL((metering_fused_kernel<T>), dim3(bpi, n_images), dim3(METER_THREADS), 0, s, a);
     MI_LAUNCH_CHECK();
     return 0;
   });
@@ -2124,32 +2068,6 @@ extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, i
   fa.nblocks = nb;
   fa.n_px = (float)((int64_t)n_images * hs * wss);
   return finalize(FIN_ISP_STATS, fa, s);
-}
-
-// update_metering on the dense subsamples the load kernels left (mi_isp_load_packed_metered; image[::stride, ::stride] of
-// H x W images): camera_isp.py:142-175 with the first pass - the bounds of the samples - folded from the per-wave pairs in
-// the buffers' tails instead of read from the samples.  Same samples, same blends; the raw bounds are the exact min / max
-// either way, so the metrics are those of mi_isp_metering on the images bit for bit.  Falls back to mi_isp_metering on the
-// samples (stride 1) where the one-launch kernel does not apply.
-extern "C" int mi_isp_metering_sub(const void* const* subs, int n_images, int H, int W, int stride, int dtype, float* state9,
-                                   float alpha, void* ws, void* stream) {
-  MI_REQUIRE(stride >= 1 && H > 0 && W > 0, "metering_sub: bad shape");
-  const int hs = (H + stride - 1) / stride, wss = (W + stride - 1) / stride;
-  if (int rc = metering_check(subs, n_images, hs, wss, 1, dtype, ws)) return rc;
-  MI_REQUIRE(state9, "metering_sub: null state");
-  hipStream_t s = (hipStream_t)stream;
-  float* fp = static_cast<float*>(ws);
-  const int cap = mi_partial_cap(hs, wss);
-  bool done = false;
-  const uint32_t tail_off = (uint32_t)mi_sub_tail_offset(H, W, stride, mi_dtype_size(dtype));
-  if (int rc = metering_fused(subs, n_images, hs, wss, 1, dtype, state9, alpha, fp, fp + FP_COUNT, cap, s, &done, tail_off)) return rc;
-  if (done) return 0;
-  return mi_isp_metering(subs, n_images, hs, wss, 1, dtype, state9, alpha, ws, stream);
-}
-
-extern "C" size_t mi_isp_metering_sub_bytes(int H, int W, int stride, int dtype) {
-  if (H <= 0 || W <= 0 || stride < 1 || !mi_valid_dtype(dtype)) return 0;
-  return mi_sub_bytes(H, W, stride, mi_dtype_size(dtype));
 }
 
 // ---- ISP tonemaps ----------------------------------------------------------------------------

@@ -69,8 +69,6 @@ struct SArgs {
   // multiple of 8 columns, so the sample of a row r % 8 == 0 is the lane's first pixel.
   void* sub;
   int sub_w;              // ceil(W / 8)
-  uint32_t sub_tail_off;  // byte offset of the subsample buffer's tail (isp_common.h: mi_sub_tail_offset); wave g leaves the
-                          // bounds of the samples it wrote as pair g there, wave 0 the pair count
   // S_STORE, several frames in one launch (grid.y = frame; mi_isp_load_packed_batch: the cameras of a group): frame y reads
   // srcs[y], writes dsts[y] (and subs[y]).  n_batch == 0: one frame, t.src / t.dst / sub.  Indexed by blockIdx.y itself
   // (a computed index would send this struct through scratch).
@@ -653,7 +651,6 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   }
 
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
-  float smin = __builtin_inff(), smax = -__builtin_inff();   // S_STORE: bounds of the metering samples this lane wrote
   Stats2 st; st.init();
   const bool want_rgb = p.ca != 0.f;                 // channel means feed mean3 only then (tonemap.py:119)
 
@@ -741,8 +738,6 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
           } else {
             sp[0] = (E)t[0]; sp[1] = (E)t[1]; sp[2] = (E)t[2];
           }
-          smin = fminf(smin, fminf(t[0], fminf(t[1], t[2])));   // (t: the stored - clamped, rounded - values)
-          smax = fmaxf(smax, fmaxf(t[0], fmaxf(t[1], t[2])));
         }
       }
       if constexpr (EPI == S_STORE || EPI == S_STORE_BOUNDS) {
@@ -832,16 +827,6 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
 #endif
   MI_SSTAMP(15);
 
-  if constexpr (EPI == S_STORE) {
-    if (sub_p && a.sub_tail_off) {                       // (uniform) the samples' bounds: pair g of the subsample's tail
-      smin = wave_min(smin); smax = wave_max(smax);
-      if (lane == 0 && wave_ok) {
-        float* tail = reinterpret_cast<float*>(static_cast<char*>(sub_p) + a.sub_tail_off);
-        tail[4 + 2 * g] = smin; tail[4 + 2 * g + 1] = smax;
-        if (g == 0) reinterpret_cast<int*>(tail)[0] = a.n_waves;
-      }
-    }
-  }
   // ---- reductions: one partial per block ----
   st.finish();
   if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); st.init(); }   // lanes beyond the image saw zeros

@@ -46,12 +46,6 @@ struct RSArgs {
   int n_batch;              // several frames in one launch (grid.y = frame): frame y reads srcs[y], writes dsts[y]; 0: t.src / t.dst
   const void* srcs[LOAD_BATCH];
   void* dsts[LOAD_BATCH];
-  // the stride-8 metering subsample of the DESTINATION image (camera_isp.py:168-170: image[::8, ::8]) written on the way,
-  // with the bounds of every wave's samples in its tail (isp_common.h: mi_sub_tail_offset); NULL: none
-  void* sub;
-  void* subs[LOAD_BATCH];
-  int sub_w;                // ceil(Wd / 8)
-  uint32_t sub_tail_off;
 };
 
 // quad origin of destination index i along one axis: min(trunc(i / s), n - 2)   (n >= 2)
@@ -91,8 +85,6 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
   const uint32_t pitch = (uint32_t)p.W * 3 / 2;
   const void* const src_p = a.n_batch > 0 ? a.srcs[blockIdx.y] : p.src;      // (blockIdx.y itself: see strm::SArgs)
   void* const dst_p = a.n_batch > 0 ? a.dsts[blockIdx.y] : p.dst;
-  half_t* const sub_p = static_cast<half_t*>(a.n_batch > 0 ? a.subs[blockIdx.y] : a.sub);
-  float smin = __builtin_inff(), smax = -__builtin_inff();      // bounds of the metering samples this lane wrote
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src_p), 0, (int)((uint32_t)p.H * pitch), 0x00020000);
   const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID_OFF;
@@ -247,15 +239,6 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
       uint32_t outp[6];
       __builtin_memcpy(outp, oh, 24);
       const int cl = gbase + 4 * lane;
-      // the metering sample of this row: destination pixels (r % 8 == 0, c % 8 == 0) - a lane's first pixel when its four
-      // start at a multiple of 8
-      if (sub_p && (r & 7) == 0 && (cl & 7) == 0 && tap[0].valid) {          // (r: wave-uniform)
-        half_t* sp = sub_p + ((size_t)(r >> 3) * a.sub_w + (size_t)(cl >> 3)) * 3;
-        sp[0] = oh[0]; sp[1] = oh[1]; sp[2] = oh[2];
-        const float s0 = (float)oh[0], s1 = (float)oh[1], s2 = (float)oh[2];
-        smin = fminf(smin, fminf(s0, fminf(s1, s2)));
-        smax = fmaxf(smax, fmaxf(s0, fmaxf(s1, s2)));
-      }
       const bool all4 = vec_rows && tap[0].valid && tap[3].valid;
       const uint32_t base = ((uint32_t)r * (uint32_t)a.Wd + (uint32_t)cl) * 6u;
       typedef uint32_t u2 __attribute__((ext_vector_type(2)));
@@ -353,14 +336,6 @@ __global__ __launch_bounds__(THREADS, 2) void resize_kernel(const RSArgs a) {
 #if MI_STREAM_PRIO
   asm volatile("s_setprio 0");
 #endif
-  if (sub_p && a.sub_tail_off) {                        // (uniform) pair g of the subsample's tail; wave 0: the pair count
-    smin = wave_min(smin); smax = wave_max(smax);
-    if (lane == 0 && wave_ok) {
-      float* tail = reinterpret_cast<float*>(reinterpret_cast<char*>(sub_p) + a.sub_tail_off);
-      tail[4 + 2 * g] = smin; tail[4 + 2 * g + 1] = smax;
-      if (g == 0) reinterpret_cast<int*>(tail)[0] = a.n_waves;
-    }
-  }
   MI_SSTAMP(5);
 }
 
