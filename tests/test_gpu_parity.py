@@ -788,9 +788,11 @@ def test_isp_metering_timeout_leaves_the_state_alone(ti, dev):
     before = isp.metrics.clone()
     assert_close(before.cpu().numpy(), m1, "metrics 1", rel=2e-5)
     assert L.mi_isp_metering_faults(1) == 0
+    # other images (the state WOULD move), without the load kernels' subsample
+    others = [(im * 0.5).contiguous() for im in imgs]
     L.mi_isp_metering_set_poll_limit(1)
     try:
-        isp.update_metering(imgs)
+        isp.update_metering(others)
         torch.cuda.synchronize()
     finally:
         L.mi_isp_metering_set_poll_limit(0)
@@ -802,8 +804,9 @@ def test_isp_metering_timeout_leaves_the_state_alone(ti, dev):
     ws[off:off + 4].zero_()
     with pytest.raises(MeteringTimeout):
         isp.update_metering(imgs)
-    isp.update_metering(imgs)                                       # the mailbox was cleared by the report: back to normal
-    assert_close(isp.metrics.cpu().numpy(), st.update_metering(refs), "metrics after the failed call", rel=2e-5)
+    isp.update_metering(others)                                     # the mailbox was cleared by the report: back to normal
+    assert not torch.equal(isp.metrics, before)
+    assert_close(isp.metrics.cpu().numpy(), st.update_metering([o.cpu().numpy() for o in others]), "metrics after the failed call", rel=2e-5)
 
 
 @pytest.mark.parametrize("cam,shape,n,kw", [("Camera16", (48, 64), 1, dict(gamma=0.6)), ("Camera16", (96, 128), 2, dict()),
