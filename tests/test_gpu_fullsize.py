@@ -471,3 +471,37 @@ def test_isp_reuse_of_tonemapped_images_full_size(ti, dev, scenes):
     from tests.util import reuse_case
     frames = [torch.from_numpy(packed_from(scenes[k], GAINS[k], OFFSETS[k])).to(dev) for k in range(2)]
     reuse_case(ti, dev, "Camera16", frames, "reinhard_twice")
+
+
+def test_default_call_inside_a_stream_capture_takes_the_multi_pass_chain(ti, dev, rng):
+    """the automatic choice must not put a whole-frame launch (which the library can neither order against other
+    resident grids nor check) into a caller's capture.  Captured with torch.cuda.graph, replayed: the multi-pass chain's
+    result, the mailbox untouched."""
+    from taichi_image_amd import _native
+    from taichi_image_amd.pipeline import pipeline12_reinhard
+    packed = natural_packed12(rng, 96, 1024)
+    f = torch.from_numpy(packed).to(dev)
+    want = pipeline12_reinhard(f, whole_frame=False).clone()
+    out = torch.empty_like(want)
+    pipeline12_reinhard(f, out=out)                                 # warm (module load, workspace) outside the capture
+    torch.cuda.synchronize()
+    calls = []
+    real = _native.lib().mi_isp_pipeline12_reinhard_whole_frame
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        pipeline12_reinhard(f, out=out)                             # the side stream's own workspace, before the capture
+        torch.cuda.synchronize()
+        _native.lib().mi_isp_pipeline12_reinhard_whole_frame = lambda *a: calls.append(a) or real(*a)
+        try:
+            with torch.cuda.graph(g, stream=s):
+                pipeline12_reinhard(f, out=out)
+        finally:
+            _native.lib().mi_isp_pipeline12_reinhard_whole_frame = real
+    assert calls == [], "the whole-frame kernel was launched inside a capture"
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert _native.lib().mi_isp_whole_frame_faults(0) == 0
