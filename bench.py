@@ -126,7 +126,9 @@ def host_frames(first, count, distinct):
     from concurrent.futures import ThreadPoolExecutor
     from taichi_image_amd import synthetic
     distinct = max(1, min(distinct, count))
-    with ThreadPoolExecutor(min(16, os.cpu_count() or 4, distinct)) as ex:
+    # (the ranks of a node generate their frames at the same time: each takes its share of the host's cores)
+    share = max(2, (os.cpu_count() or 4) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
+    with ThreadPoolExecutor(min(16, share, distinct)) as ex:
         host = list(ex.map(lambda i: synthetic.synthetic_packed12((first + i) % 64), range(distinct)))
     return host, [i % distinct for i in range(count)]
 
