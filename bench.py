@@ -304,6 +304,12 @@ def other_workloads(frames, host, device, frames_per_step):
     runs = [timed(step_b, steps, 5, device) / (steps * 6) * 1e6 for _ in range(3)]
     entry("config3_camera16_resize1920_batched_load", runs, BYTES_IN + 1440 * 1920 * 3, 6, steps,
           note="extension: ISP.load_packed12_batch (one launch for the six cameras' loads)")
+    # ... and without the reference's in-place write of the mapped values over the images (camera_isp.py:211): same u8 outputs
+    step_k = lambda: isp_b.tonemap_reinhard(isp_b.load_packed12_batch(frames[:6]), gamma=0.6, write_back=False)
+    runs = [timed(step_k, steps, 5, device) / (steps * 6) * 1e6 for _ in range(3)]
+    entry("config3_camera16_resize1920_batched_load_no_write_back", runs, BYTES_IN + 1440 * 1920 * 3, 6, steps,
+          note="extensions: load_packed12_batch + tonemap_reinhard(write_back=False): the images are NOT overwritten with p "
+               "(the reference overwrites them); same u8 outputs bit for bit")
     # config 3b: the nominal 1920x1080 through the resize primitive's per-axis scale (interpolate.py:83)
     # on the demosaiced 4K f16 image: load_packed12 at full size, resize_bilinear(scale=(0.3515625, 0.46875)) -> f16 / u8
     import taichi_image_amd as ti
@@ -327,6 +333,11 @@ def other_workloads(frames, host, device, frames_per_step):
     runs = [timed(step6b, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
     entry("reference_bench_6_cameras_full_resolution_batched_load", runs, BYTES_IN + H * W * 3, 6, 40,
           note="extension: ISP.load_packed12_batch")
+    def step6k():
+        isp6.tonemap_reinhard(isp6.load_packed12_batch(frames[:6]), gamma=0.6, write_back=False)
+    runs = [timed(step6k, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
+    entry("reference_bench_6_cameras_full_resolution_batched_load_no_write_back", runs, BYTES_IN + H * W * 3, 6, 40,
+          note="extensions: load_packed12_batch + tonemap_reinhard(write_back=False) (images not overwritten with p; same u8 outputs)")
     return res
 
 

@@ -151,6 +151,13 @@ int mi_isp_reinhard_batch(void* const* images_host, uint8_t* const* outs_host, i
                           int dtype, const float* state9_dev, float gamma, float intensity,
                           float light_adapt, float color_adapt, int transform, void* ws_dev,
                           void* stream);
+/* Extension - NOT the reference's semantics: the u8 outputs of mi_isp_reinhard_batch, bit for bit, without overwriting the
+ * images with the mapped values (camera_isp.py:211 does overwrite them).  Pass 1 only reduces, pass 2 recomputes p from the
+ * untouched image and rounds it to the image dtype as the write-back would have: a third of the two passes' bytes stays
+ * where it is.  For callers that drop the images after the tonemap, or want them as loaded. */
+int mi_isp_reinhard_batch_keep(const void* const* images_host, uint8_t* const* outs_host, int n_images, int H, int W,
+                               int dtype, const float* state9_dev, float gamma, float intensity, float light_adapt,
+                               float color_adapt, int transform, void* ws_dev, void* stream);
 int mi_isp_linear_batch(const void* const* images_host, uint8_t* const* outs_host, int n, int H,
                         int W, int dtype, const float* state9_dev, float gamma, int transform,
                         void* ws_dev, void* stream);

@@ -42,6 +42,8 @@ SIGNATURES = {
     "mi_isp_reinhard": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "mi_isp_reinhard_batch": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, _P, c_float, c_float, c_float,
                                       c_float, c_int, _P, _P]),
+    "mi_isp_reinhard_batch_keep": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, _P, c_float, c_float, c_float,
+                                           c_float, c_int, _P, _P]),
     "mi_isp_reinhard_batch_yuv420": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, _P, c_float, c_float,
                                              c_float, c_float, _P, _P]),
     "mi_isp_linear_batch": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, _P, c_float, c_int, _P, _P]),

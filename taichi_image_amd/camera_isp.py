@@ -429,9 +429,12 @@ def camera_isp(name: str, dtype=types.f32):
 
         def tonemap_reinhard(self, images: List[torch.Tensor],
                              gamma: float = 1.0, intensity: float = 1.0, light_adapt: float = 1.0,
-                             color_adapt: float = 0.0):
+                             color_adapt: float = 0.0, write_back: bool = True):
             """camera_isp.py:394-403.  NOTE: like the reference, pass 1 overwrites each input image
-            with the Reinhard-mapped values (camera_isp.py:211)."""
+            with the Reinhard-mapped values (camera_isp.py:211).
+            write_back=False (an extension, not the reference's semantics): the same u8 outputs, bit for bit, with the
+            images left as they are - a third of the tonemap's memory traffic is that write and its re-read."""
+            _typecheck("write_back", write_back, bool)
             _typecheck("images", images, list)
             for n, v in (("gamma", gamma), ("intensity", intensity), ("light_adapt", light_adapt),
                          ("color_adapt", color_adapt)):
@@ -443,11 +446,13 @@ def camera_isp(name: str, dtype=types.f32):
             # orientation transform (:403) is folded into the u8 store
             H, W = images[0].shape[:2]
             ws = _native.workspace(H, W, self.device)
-            _native.check(_native.lib().mi_isp_reinhard_batch(
+            fn = _native.lib().mi_isp_reinhard_batch if write_back else _native.lib().mi_isp_reinhard_batch_keep
+            _native.check(fn(
                 _native.ptr_array(images), _native.ptr_array(outputs), len(images), H, W, dtype.code,
                 self.metrics.data_ptr(), float(gamma), float(intensity), float(light_adapt), float(color_adapt),
                 interpolate.transform_code(self.transform), ws.data_ptr(), _native.stream_ptr(self.device)))
-            _written_in_place(images)
+            if write_back:
+                _written_in_place(images)
             return outputs
 
         def tonemap_reinhard_yuv420(self, images: List[torch.Tensor],

@@ -465,7 +465,10 @@ enum PassMode {
   PM_RH_STORE = 3,      // + final linear_func (tonemap.py:154)
   PM_LINEAR_STORE = 4,  // tonemap_linear / ISP linear_kernel: linear_func straight to dst
   PM_ISP_RH_P1 = 5,     // camera_isp.py:198-213: p written back in place, max(p)
-  PM_ISP_RH_P2 = 6      // camera_isp.py:215-218: (p/max_out)^(1/gamma)*255 -> u8
+  PM_ISP_RH_P2 = 6,     // camera_isp.py:215-218: (p/max_out)^(1/gamma)*255 -> u8
+  PM_ISP_RH_P2R = 7     // the same from the UNTOUCHED image: p recomputed (camera_isp.py:198-211) and rounded to the image dtype as
+                        // the write-back would have, for pass 1 run without its write-back (ISP.tonemap_reinhard(write_back=False),
+                        // an extension: the reference's images are mutated, these are not; the u8 outputs are the same bits)
 };
 
 struct PassArgs {
@@ -492,6 +495,7 @@ struct PassArgs {
   const float* isp_state9;  // PM_ISP_RH_P1: camera_isp.py:186-195 evaluated per block (NULL: read fp)
   int no_nan;               // the source image holds no NaN (written by the tile kernel's clamping store)
   int pull_maxout_n;        // PM_ISP_RH_P2: partial maxima per image at partials[part_stride + y * n + i] (0: read maxouts)
+  int no_writeback;         // PM_ISP_RH_P1: p is not written back over the image (pass 2 is then PM_ISP_RH_P2R)
   int part_flip;            // PM_ISP_RH_P2, batched: grid row y reads the partial maxima of row n - 1 - y (pass 1 ran over the
                             // reversed list, see mi_isp_reinhard_batch)
 };
@@ -577,7 +581,7 @@ MI_DEV void pull_finalize(const PassArgs& a, float* sh_fp, double (*sh_tot)[PASS
 
 // per-wave LDS staging of the wave-cooperative stores decides whether two 1024-thread blocks fit a CU
 template <class TI, class TO, int MODE> constexpr int pass_lds_bytes() {
-  const bool uses_io = MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2 || MODE == PM_ISP_RH_P1;
+  const bool uses_io = MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2 || MODE == PM_ISP_RH_P2R || MODE == PM_ISP_RH_P1;
   return uses_io ? (PASS_THREADS / 64) * 64 * 24 * (int)(sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO)) : 0;
 }
 template <class TI, class TO, int MODE>
@@ -594,7 +598,8 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   const int64_t n_groups = (a.n_px + 7) / 8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  constexpr bool STORES = MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || MODE == PM_ISP_RH_P2;
+  constexpr bool P2ANY = MODE == PM_ISP_RH_P2 || MODE == PM_ISP_RH_P2R;
+  constexpr bool STORES = MODE == PM_RH_STORE || MODE == PM_LINEAR_STORE || P2ANY;
 
   // the pass's scalars: from the pulled finalize of the producer's partials, or from FrameParams
   __shared__ float sh_fp[FP_COUNT];
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
     if (pulled) pull_finalize<PULL_FIN>(a, sh_fp, sh_tot);
   }
   bool isp_prep = false;
-  if constexpr (MODE == PM_ISP_RH_P1) {
+  if constexpr (MODE == PM_ISP_RH_P1 || MODE == PM_ISP_RH_P2R) {
     isp_prep = a.isp_state9 != nullptr;
     if (isp_prep) {
       if (threadIdx.x == 0) isp_reinhard_scalars(a.isp_state9, sh_fp, a.pull_intensity, a.ca);
@@ -637,12 +642,13 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   ReinhardK rk;
   rk.la = a.la; rk.ca = a.ca; rk.map_key = 1.f; rk.ei = 1.f; rk.mean3[0] = rk.mean3[1] = rk.mean3[2] = 0.f;
   if (MODE != PM_MINMAX && MODE != PM_ISP_RH_P2) { lo = fpv(FP_LO); inv = fpv(FP_INV); }
-  if (MODE == PM_RH_MINMAX || MODE == PM_RH_STORE || MODE == PM_ISP_RH_P1) {
+  if (MODE == PM_RH_MINMAX || MODE == PM_RH_STORE || MODE == PM_ISP_RH_P1 || MODE == PM_ISP_RH_P2R) {
     rk.map_key = fpv(FP_MAPKEY); rk.ei = fpv(FP_EI);
     rk.mean3[0] = fpv(FP_MEAN3); rk.mean3[1] = fpv(FP_MEAN3 + 1); rk.mean3[2] = fpv(FP_MEAN3 + 2);
   }
   if (MODE == PM_RH_STORE) { lo2 = fpv(FP_LO2); inv2 = fpv(FP_INV2); }
-  if constexpr (MODE == PM_ISP_RH_P2) {
+  if constexpr (P2ANY) {
+    if constexpr (MODE == PM_ISP_RH_P2R) __syncthreads();     // (the scalars above were read out of sh_fp, which the fold re-uses)
     if (a.batched && a.pull_maxout_n > 0) {
       // max_out of this block's image (camera_isp.py:190,213): fold the partial maxima pass 1 left
       const int prow = a.part_flip ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
@@ -712,6 +718,14 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
       } else if (MODE == PM_ISP_RH_P2) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = x[ch] * maxout_inv;
+      } else if (MODE == PM_ISP_RH_P2R) {
+        // p as pass 1 computes it (camera_isp.py:200-210), rounded to the image dtype as the write-back stores it (:211)
+        float t[3], q[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) t[ch] = (x[ch] - lo) * inv;
+        reinhard_px<CA0>(t, rk, q);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = (float)cast_out<TI>(q[ch]) * maxout_inv;
       } else {
         float t[3];
 #pragma unroll
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
         }
       }
     }
-    if (MODE == PM_ISP_RH_P2) {                      // camera_isp.py:217-218 (no clamp there)
+    if (P2ANY) {                                     // camera_isp.py:217-218 (no clamp there)
       if (a.gamma_inv != 1.f) {
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -744,7 +758,9 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
     }
     if (MODE == PM_LINEAR_STORE) linear_n<24>(o, lo, inv, a.gamma_inv, a.out_scale);
     if (MODE == PM_RH_STORE) linear_n<24>(o, lo2, inv2, a.gamma_inv, a.out_scale);
-    if (MODE == PM_ISP_RH_P1) {
+    if (MODE == PM_ISP_RH_P1 && a.no_writeback) {
+      // (nothing to store: pass 2 recomputes p from the image)
+    } else if (MODE == PM_ISP_RH_P1) {
       if constexpr (FULL) {
         TI ot[24];
 #pragma unroll
@@ -793,7 +809,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
   // (only for images the tile kernel wrote - a.no_nan: its clamp has already mapped NaN to 0, which norm01 would do here)
   const bool unit_bounds = (MODE == PM_STATS || MODE == PM_RH_MINMAX || MODE == PM_RH_STORE) && a.no_nan && lo == 0.f && inv == 1.f;
   // the colour-adapt variant (three pows per pixel) only exists for the modes that evaluate reinhard_px
-  constexpr bool HAS_REINHARD = MODE == PM_RH_MINMAX || MODE == PM_RH_STORE || MODE == PM_ISP_RH_P1;
+  constexpr bool HAS_REINHARD = MODE == PM_RH_MINMAX || MODE == PM_RH_STORE || MODE == PM_ISP_RH_P1 || MODE == PM_ISP_RH_P2R;
   if (!HAS_REINHARD || rk.ca == 0.f) {
     for (int64_t g = tid; g < n_full; g += PREFETCH * stride) {
 #pragma unroll
@@ -1506,7 +1522,7 @@ static int launch_pass_t(int mode, const PassArgs& a, int nblocks, hipStream_t s
     break;
   switch (mode) {
     MI_PASS(PM_MINMAX) MI_PASS(PM_STATS) MI_PASS(PM_RH_MINMAX) MI_PASS(PM_RH_STORE)
-    MI_PASS(PM_LINEAR_STORE) MI_PASS(PM_ISP_RH_P1) MI_PASS(PM_ISP_RH_P2)
+    MI_PASS(PM_LINEAR_STORE) MI_PASS(PM_ISP_RH_P1) MI_PASS(PM_ISP_RH_P2) MI_PASS(PM_ISP_RH_P2R)
     default: mi_set_error("bad pass mode %d", mode); return 1;
   }
 #undef MI_PASS
@@ -2208,9 +2224,9 @@ extern "C" int mi_isp_reinhard_faults(int clear) {
 
 // N images of one tonemap_reinhard call (camera_isp.py:399-403) with 4 launches in total instead of
 // 4 per image: prep, pass 1 over all images (grid.y = image), per-image max_out, pass 2 over all.
-extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
-                                     const float* state9, float gamma, float intensity, float light_adapt,
-                                     float color_adapt, int transform, void* ws, void* stream) {
+static int reinhard_batch_impl(void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
+                               const float* state9, float gamma, float intensity, float light_adapt,
+                               float color_adapt, int transform, void* ws, void* stream, bool write_back) {
   MI_REQUIRE(images && outs && state9 && ws, "reinhard_batch: null pointer");
   MI_REQUIRE(n >= 0, "reinhard_batch: negative image count");
   MI_REQUIRE(H > 0 && W > 0, "reinhard_batch: bad shape");
@@ -2228,9 +2244,10 @@ extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, 
     {
       for (int i = 0; i < m; ++i) MI_REQUIRE(images[i0 + i] && outs[i0 + i], "reinhard_batch: image %d is null", i0 + i);
       bool done = false;                                       // one persistent launch when the group's p fits the chip
-      if (int rc = isp_reinhard_fused(images + i0, outs + i0, m, H, W, dtype, state9, gamma, intensity, light_adapt,
-                                      color_adapt, transform, fp, s, &done))
-        return rc;
+      if (write_back)
+        if (int rc = isp_reinhard_fused(images + i0, outs + i0, m, H, W, dtype, state9, gamma, intensity, light_adapt,
+                                        color_adapt, transform, fp, s, &done))
+          return rc;
       if (done) continue;
     }
     PassArgs a = {};
@@ -2264,13 +2281,32 @@ extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, 
       }
     };
     set_lists(order1);
+    a.no_writeback = write_back ? 0 : 1;
     if (int rc = launch_pass(PM_ISP_RH_P1, dtype, MI_U8, a, nb, s, m)) return rc;
     a.pull_maxout_n = nb;                                    // max_out per image folded in pass 2's prologue
     set_lists(order2);
     a.part_flip = order1 != order2;                          // pass 1 left image j's maxima in the row of ITS list position
-    if (int rc = launch_pass(PM_ISP_RH_P2, dtype, MI_U8, a, nb, s, m)) return rc;
+    // without the write-back pass 2 derives p again from the untouched image (and rounds it as the write-back would have)
+    if (int rc = launch_pass(write_back ? PM_ISP_RH_P2 : PM_ISP_RH_P2R, dtype, MI_U8, a, nb, s, m)) return rc;
   }
   return 0;
+}
+
+extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
+                                     const float* state9, float gamma, float intensity, float light_adapt,
+                                     float color_adapt, int transform, void* ws, void* stream) {
+  return reinhard_batch_impl(images, outs, n, H, W, dtype, state9, gamma, intensity, light_adapt, color_adapt, transform, ws,
+                             stream, true);
+}
+
+// Extension (not the reference's semantics): the same u8 outputs WITHOUT overwriting the images with p (camera_isp.py:211) -
+// for callers that drop or re-use the images as they were.  Pass 1 only reduces, pass 2 recomputes p: a third of the two
+// passes' bytes (the write of p and its re-read) is not moved.
+extern "C" int mi_isp_reinhard_batch_keep(const void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
+                                          const float* state9, float gamma, float intensity, float light_adapt,
+                                          float color_adapt, int transform, void* ws, void* stream) {
+  return reinhard_batch_impl(const_cast<void* const*>(images), outs, n, H, W, dtype, state9, gamma, intensity, light_adapt,
+                             color_adapt, transform, ws, stream, false);
 }
 
 // tonemap_reinhard of a list of images straight to planar YUV 4:2:0 (u8): pass 1 as in mi_isp_reinhard_batch (the images

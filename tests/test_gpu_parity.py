@@ -849,6 +849,31 @@ def test_isp_reinhard_in_one_launch_equals_two_passes(ti, dev, cam, shape, n, kw
     assert _native.lib().mi_isp_reinhard_faults(1) == 0
 
 
+@pytest.mark.parametrize("cam,shape,n,kw", [("Camera16", (200, 512), 3, dict(gamma=0.6)), ("Camera32", (96, 128), 2, dict(gamma=2.2, color_adapt=0.3)),
+                                            ("Camera16", (70, 200), 2, dict()), ("Camera16", (768, 1024), 6, dict(gamma=0.8, intensity=1.2, light_adapt=0.6))])
+def test_isp_tonemap_reinhard_without_write_back(ti, dev, cam, shape, n, kw):
+    """Extension: tonemap_reinhard(write_back=False) gives the u8 outputs and metrics of the default call bit for bit and
+    leaves the images (and their metering subsample tags) untouched - the default overwrites them (camera_isp.py:211)."""
+    H, W = shape
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(900 + k), H, W, dark=0.03 * k)).to(dev) for k in range(n)]
+    for transform in (ti.interpolate.ImageTransform.none, ti.interpolate.ImageTransform.rotate_90):
+        a = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.4, transform=transform, device=dev)
+        b = getattr(ti, cam)(ti.BayerPattern.RGGB, moving_alpha=0.4, transform=transform, device=dev)
+        for step in range(2):
+            ia, ib = [a.load_packed12(f) for f in frames], [b.load_packed12(f) for f in frames]
+            before = [im.clone() for im in ib]
+            tags = [hasattr(im, "_mi_metering_sub") for im in ib]
+            oa = a.tonemap_reinhard(ia, **kw)
+            ob = b.tonemap_reinhard(ib, write_back=False, **kw)
+            assert torch.equal(a.metrics, b.metrics)
+            bits = torch.int16 if cam == "Camera16" else torch.int32
+            for k in range(n):
+                assert torch.equal(oa[k], ob[k]), f"step {step} image {k}: u8 output differs"
+                assert torch.equal(ib[k].view(bits), before[k].view(bits)), "write_back=False changed the image"
+                assert hasattr(ib[k], "_mi_metering_sub") == tags[k]
+                assert not torch.equal(ia[k].view(bits), before[k].view(bits)), "the default call did not write p back"
+
+
 def test_isp_reinhard_one_launch_timeout_is_reported(ti, dev, monkeypatch):
     """The fused tonemap's wait for max_out with a budget of one poll: a block that looks before the others have arrived
     gives up - fault word, mailbox, TonemapTimeout at the next call - and nothing hangs; the call after that is clean."""
