@@ -15,7 +15,11 @@ MI_DEV float hw_pow(float b, float e) { return hw_exp2(e * hw_log2(b)); }
 MI_DEV float hw_log(float x) { return hw_log2(x) * 0.6931471805599453f; }
 
 // color/__init__.py:7-10
-MI_DEV float rgb_gray(float r, float g, float b) { return (r * 0.299f + g * 0.587f) + b * 0.114f; }
+// Written with explicit fmas (round 4): under `contract(fast)` WHICH of the two products of (r .299 + g .587) is fused is
+// the compiler's choice per instantiation, and two kernels that must derive the same bits from the same pixel - pass 1 of
+// the ISP Reinhard and the recomputing pass 2 of tonemap_reinhard(write_back=False) - differed in the last bit of the gray.
+// This is the form the compiler had picked in the whole-frame kernel: g .587 first, then r, then b.
+MI_DEV float rgb_gray(float r, float g, float b) { return __builtin_fmaf(b, 0.114f, __builtin_fmaf(r, 0.299f, g * 0.587f)); }
 
 // clamp to [0, 1] in one instruction (v_med3_f32; a NaN input yields min3 of the others = 0)
 MI_DEV float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
@@ -51,7 +55,7 @@ struct ReinhardK {
 // the adaptation term the three channels of a pixel share when color_adapt == 0 (tonemap.py:120-129)
 MI_DEV float reinhard_adapt_ca0(const float (&t)[3], const ReinhardK& k) {
   const float g = rgb_gray(t[0], t[1], t[2]);
-  const float am = k.mean3[0] + k.la * (g - k.mean3[0]);
+  const float am = __builtin_fmaf(k.la, g - k.mean3[0], k.mean3[0]);
   return hw_pow(k.ei * am, k.map_key);
 }
 // one channel: t / (ad + t)
@@ -67,8 +71,8 @@ MI_DEV void reinhard_px(const float (&t)[3], const ReinhardK& k, float (&out)[3]
     const float g = rgb_gray(t[0], t[1], t[2]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float ac = g + k.ca * (t[c] - g);
-      const float am = k.mean3[c] + k.la * (ac - k.mean3[c]);
+      const float ac = __builtin_fmaf(k.ca, t[c] - g, g);
+      const float am = __builtin_fmaf(k.la, ac - k.mean3[c], k.mean3[c]);
       const float ad = hw_pow(k.ei * am, k.map_key);
       out[c] = t[c] * hw_rcp(ad + t[c]);
     }
