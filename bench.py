@@ -309,7 +309,8 @@ def other_workloads(frames, host, device, frames_per_step):
     runs = [timed(step_k, steps, 5, device) / (steps * 6) * 1e6 for _ in range(3)]
     entry("config3_camera16_resize1920_batched_load_no_write_back", runs, BYTES_IN + 1440 * 1920 * 3, 6, steps,
           note="extensions: load_packed12_batch + tonemap_reinhard(write_back=False): the images are NOT overwritten with p "
-               "(the reference overwrites them); same u8 outputs bit for bit")
+               "(the reference overwrites them); same u8 outputs bit for bit.  At this image size the second evaluation of "
+               "Reinhard costs more than the bytes it saves: slower than the line above; it pays at full resolution (below)")
     # config 3b: the nominal 1920x1080 through the resize primitive's per-axis scale (interpolate.py:83)
     # on the demosaiced 4K f16 image: load_packed12 at full size, resize_bilinear(scale=(0.3515625, 0.46875)) -> f16 / u8
     import taichi_image_amd as ti
