@@ -892,9 +892,15 @@ struct IspFusedArgs {
   struct IO { void* img; uint8_t* out; } io[ISPF_MAX_IMAGES];
 };
 
-template <class TI, bool CA0, int MAXIT, bool PIPE, int BPC>
+// NLDS: the last NLDS of a thread's MAXIT groups keep their p in LDS ([group][16-byte unit][thread]: a wave's accesses are
+// contiguous) instead of registers - what lets a 4096 x 3072 f16 frame (12 groups per thread: 7 in 84 registers, 5 in 60 KB
+// of LDS per block) stay on the chip between the passes.
+template <class TI, bool CA0, int MAXIT, bool PIPE, int BPC, int NLDS = 0>
 __global__ __launch_bounds__(ISPF_THREADS, BPC) void isp_reinhard_fused_kernel(const IspFusedArgs a) {
 #pragma clang fp contract(fast)
+  static_assert(NLDS == 0 || (!PIPE && sizeof(TI) == 2), "LDS-kept groups: one image at a time, f16");
+  constexpr int NREG = MAXIT - NLDS;
+  __shared__ __attribute__((aligned(16))) uint4 lds_keep[NLDS > 0 ? NLDS : 1][3][NLDS > 0 ? ISPF_THREADS : 1];
   __shared__ float sh_fp[FP_COUNT];
   __shared__ float sh_red[ISPF_THREADS / 64];
   __shared__ float sh_max[2];
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(ISPF_THREADS, BPC) void isp_reinhard_fused_kernel(c
   rk.mean3[0] = sh_fp[FP_MEAN3]; rk.mean3[1] = sh_fp[FP_MEAN3 + 1]; rk.mean3[2] = sh_fp[FP_MEAN3 + 2];
 
   constexpr int SLOTS = PIPE ? 2 : 1;
-  Raw24<TI> keep[SLOTS][MAXIT];
+  Raw24<TI> keep[SLOTS][NREG];
   Raw24<TI> raw;                                             // the group in flight (see p1)
   if (tid < a.n_groups) load24_raw<TI>(static_cast<const TI*>(a.io[0].img) + tid * 24, raw);
 
@@ -953,12 +959,19 @@ __global__ __launch_bounds__(ISPF_THREADS, BPC) void isp_reinhard_fused_kernel(c
           uint32_t w[12];
 #pragma unroll
           for (int j = 0; j < 12; ++j) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w[j]) : "v"(o[2 * j]), "v"(o[2 * j + 1]));
-          __builtin_memcpy(&keep[S][IT], w, sizeof(w));
+          if constexpr (IT < NREG) {
+            __builtin_memcpy(&keep[S][IT], w, sizeof(w));
+          } else {
+            uint4 u[3];
+            __builtin_memcpy(u, w, sizeof(w));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) lds_keep[IT - NREG][j][threadIdx.x] = u[j];
+          }
           __builtin_memcpy(ot, w, sizeof(w));
         } else {
 #pragma unroll
           for (int i = 0; i < 24; ++i) ot[i] = cast_out<TI>(o[i]);
-          __builtin_memcpy(&keep[S][IT], ot, sizeof(ot));
+          __builtin_memcpy(&keep[S][IT < NREG ? IT : 0], ot, sizeof(ot));
         }
         wave_store24<TI, false>(img + (g - lane) * 24, lane, wbuf, ot);            // camera_isp.py:211
       }
@@ -1022,7 +1035,16 @@ __global__ __launch_bounds__(ISPF_THREADS, BPC) void isp_reinhard_fused_kernel(c
       const int64_t g = tid + IT * stride;
       if (IT < a.iters && g < a.n_groups) {
         float o[24];
-        raw_to_float<TI>(keep[S][IT], o);                    // (through an opaque copy of the packed words)
+        if constexpr (IT < NREG) {
+          raw_to_float<TI>(keep[S][IT], o);                  // (through an opaque copy of the packed words)
+        } else {
+          Raw24<TI> r;
+          uint4 u[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) u[j] = lds_keep[IT - NREG][j][threadIdx.x];
+          __builtin_memcpy(&r, u, sizeof(u));
+          raw_to_float<TI>(r, o);
+        }
 #pragma unroll
         for (int i = 0; i < 24; ++i) o[i] *= maxout_inv;
         if (a.gamma_inv != 1.f) {
@@ -2120,16 +2142,16 @@ extern "C" int mi_isp_reinhard(void* image, uint8_t* out, int H, int W, int dtyp
 // groups, every image's p resident (<= MAXIT groups per thread).  *done = false: the caller takes the two-pass path.
 static std::atomic<unsigned> g_ispf_poll_limit{0};
 static struct { unsigned* buf[16] = {}; unsigned launches[16] = {}; int bpc[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}; } g_ispf;
-template <class TI, bool CA0, int MAXIT, bool PIPE, int BPC>
+template <class TI, bool CA0, int MAXIT, bool PIPE, int BPC, int NLDS = 0>
 static int ispf_launch(const IspFusedArgs& a, int nblocks, int slot, hipStream_t s, bool* ok) {
   if (g_ispf.bpc[slot] < 0) {
     int per_cu = 0;
-    MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE, BPC>, ISPF_THREADS, 0));
+    MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE, BPC, NLDS>, ISPF_THREADS, 0));
     g_ispf.bpc[slot] = per_cu;
   }
   *ok = g_ispf.bpc[slot] >= BPC;                             // every block resident, or not at all
   if (!*ok) return 0;
-  hipLaunchKernelGGL((isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE, BPC>), dim3(nblocks), dim3(ISPF_THREADS), 0, s, a);
+  hipLaunchKernelGGL((isp_reinhard_fused_kernel<TI, CA0, MAXIT, PIPE, BPC, NLDS>), dim3(nblocks), dim3(ISPF_THREADS), 0, s, a);
   MI_LAUNCH_CHECK();
   return 0;
 }
@@ -2144,7 +2166,8 @@ static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, 
   // within an image), and a block-wide hand-over per image.  So it is OFF unless MI_ISP_REINHARD_LAUNCHES=1 asks for it
   // (read per call; tests/ compare the two paths bit for bit).
   const char* env = getenv("MI_ISP_REINHARD_LAUNCHES");
-  if (!(env && atoi(env) == 1)) return 0;
+  const int forced = env ? atoi(env) : 0;
+  if (forced == 2) return 0;
   if (transform != MI_T_NONE || m < 1 || m > ISPF_MAX_IMAGES) return 0;
   const int64_t n_px = (int64_t)H * W;
   if (n_px % 512 != 0) return 0;                               // whole waves of whole groups only
@@ -2164,7 +2187,12 @@ static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, 
   if ((int64_t)nblocks * ISPF_THREADS > n_groups) nblocks = (int)(n_groups / ISPF_THREADS) > 0 ? (int)(n_groups / ISPF_THREADS) : 1;
   const int iters = (int)((n_groups + (int64_t)nblocks * ISPF_THREADS - 1) / ((int64_t)nblocks * ISPF_THREADS));
   const bool pipe = iters <= 3 && m > 1;
-  if (!pipe && iters > (f16 ? 6 : 4)) return 0;              // (what the registers hold next to the working set)
+  // LARGE images (7 - 12 groups per thread, f16: a 4096 x 3072 frame has 12): 7 groups in registers, 5 in LDS, one image at a
+  // time.  Here the two passes are bound by memory - six 4K cameras are 453 MB of p, written, evicted and read again - and the
+  // kept p saves pass 2 its 75 MB per image: this form is the DEFAULT for such images; the small-image forms stay opt-in.
+  const bool large = f16 && !pipe && iters > 6 && iters <= 12;
+  if (!large && forced != 1) return 0;
+  if (!pipe && !large && iters > (f16 ? 6 : 4)) return 0;     // (what the registers hold next to the working set)
   IspFusedArgs a = {};
   a.n_images = m; a.iters = iters; a.n_groups = n_groups;
   a.gamma_inv = (float)(1.0 / (double)gamma); a.intensity = intensity; a.la = la; a.ca = ca; a.state9 = state9;
@@ -2188,9 +2216,12 @@ static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, 
   bool ok = false;
   int rc = 0;
   const bool ca0 = ca == 0.f;
-  const int slot = (f16 ? 0 : 4) + (ca0 ? 0 : 2) + (pipe ? 0 : 1);
+  const int slot = large ? 8 + (ca0 ? 0 : 1) : (f16 ? 0 : 4) + (ca0 ? 0 : 2) + (pipe ? 0 : 1);
 #define MI_ISPF(TI, CA0, MAXIT, PIPE, BPC) rc = ispf_launch<TI, CA0, MAXIT, PIPE, BPC>(a, nblocks, slot, s, &ok)
-  if (f16) {
+  if (large) {
+    if (ca0) rc = ispf_launch<half_t, true, 12, false, 2, 5>(a, nblocks, slot, s, &ok);
+    else rc = ispf_launch<half_t, false, 12, false, 2, 5>(a, nblocks, slot, s, &ok);
+  } else if (f16) {
     if (ca0) { if (pipe) MI_ISPF(half_t, true, 3, true, 2); else MI_ISPF(half_t, true, 6, false, 2); }
     else     { if (pipe) MI_ISPF(half_t, false, 3, true, 2); else MI_ISPF(half_t, false, 6, false, 2); }
   } else {

@@ -505,3 +505,28 @@ def test_default_call_inside_a_stream_capture_takes_the_multi_pass_chain(ti, dev
     torch.cuda.synchronize()
     assert torch.equal(out, want)
     assert _native.lib().mi_isp_whole_frame_faults(0) == 0
+
+
+def test_isp_reinhard_4k_one_launch_equals_two_passes(ti, dev, scenes, monkeypatch):
+    """4096 x 3072 f16 images take the one-launch Reinhard by default (12 groups per thread: 7 kept in registers, 5 in LDS,
+    one image at a time): in-place p, u8 outputs and metrics equal those of the two passes bit for bit, three cameras."""
+    frames = [torch.from_numpy(packed_from(scenes[k], GAINS[k], OFFSETS[k])).to(dev) for k in range(3)]
+
+    def run(two_pass):
+        if two_pass:
+            monkeypatch.setenv("MI_ISP_REINHARD_LAUNCHES", "2")
+        else:
+            monkeypatch.delenv("MI_ISP_REINHARD_LAUNCHES", raising=False)
+        isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+        imgs = [isp.load_packed12(f) for f in frames]
+        outs = isp.tonemap_reinhard(imgs, gamma=0.6)
+        torch.cuda.synchronize()
+        return imgs, outs, isp.metrics.clone()
+    i1, o1, m1 = run(False)
+    i2, o2, m2 = run(True)
+    assert torch.equal(m1, m2)
+    for k in range(3):
+        assert torch.equal(o1[k], o2[k]), f"image {k}: u8 output differs"
+        assert torch.equal(i1[k].view(torch.int16), i2[k].view(torch.int16)), f"image {k}: in-place p differs"
+    from taichi_image_amd import _native
+    assert _native.lib().mi_isp_reinhard_faults(1) == 0
