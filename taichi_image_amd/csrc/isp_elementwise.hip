@@ -2188,10 +2188,11 @@ static int isp_reinhard_fused(void* const* images, uint8_t* const* outs, int m, 
   const int iters = (int)((n_groups + (int64_t)nblocks * ISPF_THREADS - 1) / ((int64_t)nblocks * ISPF_THREADS));
   const bool pipe = iters <= 3 && m > 1;
   // LARGE images (7 - 12 groups per thread, f16: a 4096 x 3072 frame has 12): 7 groups in registers, 5 in LDS, one image at a
-  // time.  Here the two passes are bound by memory - six 4K cameras are 453 MB of p, written, evicted and read again - and the
-  // kept p saves pass 2 its 75 MB per image: this form is the DEFAULT for such images; the small-image forms stay opt-in.
+  // time.  MEASURED (six 4K cameras): bit-identical and much SLOWER - 0.53 - 0.54 ms per step against 0.44 - 0.45.  A frame's p is
+  // 295 KB per CU; what is left of the register file next to it holds ONE 3 KB group in flight per wave, 8 waves per CU: 6 MB
+  // in flight on the whole chip, where 6.5 TB/s x 2 us of latency want 13.  The two passes run 32 waves per CU.  Opt-in too.
   const bool large = f16 && !pipe && iters > 6 && iters <= 12;
-  if (!large && forced != 1) return 0;
+  if (forced != 1) return 0;
   if (!pipe && !large && iters > (f16 ? 6 : 4)) return 0;     // (what the registers hold next to the working set)
   IspFusedArgs a = {};
   a.n_images = m; a.iters = iters; a.n_groups = n_groups;
