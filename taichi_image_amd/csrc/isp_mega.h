@@ -70,28 +70,6 @@ using namespace strm;
 #endif
 #endif
 
-#ifndef MI_MEGA_PRIO                     /* how the two waves of a SIMD share its issue slots: prio_turn() */
-#define MI_MEGA_PRIO 1
-#endif
-#ifndef MI_MEGA_PRIO_D                   /* turns in phase D too: measured, nothing (46.0 either way; non-unit frames 54.5 against 54.0) */
-#define MI_MEGA_PRIO_D 0
-#endif
-#ifndef MI_MEGA_PRIO_ROWS
-#define MI_MEGA_PRIO_ROWS 1
-#endif
-#ifndef MI_MEGA_PRIO_LEVEL
-#define MI_MEGA_PRIO_LEVEL 1
-#endif
-#ifndef MI_MEGA_PRIO_C_SHIFT             /* phase C: a turn per 2^shift rows */
-#define MI_MEGA_PRIO_C_SHIFT 0
-#endif
-#ifndef MI_MEGA_PRIO_TURN_SHIFT
-#define MI_MEGA_PRIO_TURN_SHIFT 0
-#endif
-#ifndef MI_MEGA_PRIO_SHIFT
-#define MI_MEGA_PRIO_SHIFT 11            /* slices of 2048 cycles (~1 us) */
-#endif
-
 constexpr int ROWS = 12;             // rows per wave
 constexpr int NL = 5;                // of which live in LDS ...
 constexpr int NR = ROWS - NL;        // ... and in registers
@@ -110,9 +88,7 @@ constexpr int ROW_U4 = 64 * 3;       // one f16 row of a wave: 64 lanes x 3 x 16
 #endif
 constexpr int REC = MI_MEGA_REC;
 constexpr int MROW_BAR0 = strm::MEGA_ROW_BASE, MROW_BAR1 = MROW_BAR0 + 8, MROW_BAR2 = MROW_BAR1 + 8;
-// Two-level barriers (round 4): behind the three record areas one partial row per barrier for the RESULTS - the scalars
-// an XCD's leader derived, one 256-byte slot per XCD - and one row of claim words (64 bytes apart: barrier * 8 + XCD).
-constexpr int MROW_RES = MROW_BAR2 + 8, MROW_CLAIM = MROW_RES + 3, MROW_END = MROW_CLAIM + 1;
+constexpr int MROW_END = MROW_BAR2 + 8;
 static_assert(MROW_END <= strm::PART_ROWS, "the whole-frame kernel's rows must fit the workspace");
 static_assert(REC >= 64 && REC % 16 == 0, "three 16-byte chunks and the beacon per record");
 constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside FrameParams (slots no pass uses)
@@ -129,9 +105,6 @@ constexpr int FP_EPOCH = 60, FP_ERROR = 62;           // uint32 words inside Fra
 // check word of a record chunk: two multiplies and a shift (a torn chunk passes only if the words that differ collide
 // in 32 bits of a multiplicative hash)
 MI_DEV uint32_t rec_hash(uint32_t x, uint32_t y, uint32_t z) {
-#ifdef MI_MEGA_NO_HASH
-  return 0u;
-#endif
   uint32_t h = ((x * 0x9E3779B1u) ^ y) * 0x85EBCA6Bu ^ z;
   return h ^ (h >> 15);
 }
@@ -191,53 +164,8 @@ MI_DEV float wsum(float v) {
 #undef MI_DPP_TREE
 #undef MI_DPP_STEP
 
-// the normalisation of phases C and D (frames whose bounds are not (0, 1)) as one fma.  Measured on one box, unit / non-unit
-// frames: 44.05 / 50.13 us with it, 43.81 / 50.90 without - the frames it is not executed for pay 0.24 us for the other
-// arm's different register allocation.  Off: the headline is the unit frame.
-#ifndef MI_MEGA_NORM_FMA
-#define MI_MEGA_NORM_FMA 0
-#endif
 #ifndef MI_MEGA_FLAG_SLEEP            /* units of 64 cycles between two looks at the block's LDS flag; swept: 0 43.70, 1 43.86, 2 43.66, 4 43.77 us */
 #define MI_MEGA_FLAG_SLEEP 2
-#endif
-#ifndef MI_MEGA_LATE_SKIPS_L2         /* measured: 44.02 us per frame against 43.83 - see barrier_fold */
-#define MI_MEGA_LATE_SKIPS_L2 0
-#endif
-#ifndef MI_MEGA_EAGER_ROUND           /* measured: 47.0 us per frame against 44.2 - see barrier_fold */
-#define MI_MEGA_EAGER_ROUND 0
-#endif
-#ifndef MI_MEGA_ASM_REDUCE
-#define MI_MEGA_ASM_REDUCE 1
-#endif
-#if defined(MI_MEGA_DENSE) && MI_MEGA_DENSE && defined(MI_MEGA_TWO_LEVEL) && !MI_MEGA_TWO_LEVEL
-#error "dense records are for the two-level barrier (no watch stage, 32 pollers)"
-#endif
-#ifndef MI_MEGA_TWO_LEVEL             /* one block per XCD folds the records, the others take its result from the L2: measured, no gain (barrier_fold) */
-#define MI_MEGA_TWO_LEVEL 0
-#endif
-#ifndef MI_MEGA_LEADER_WATCH          /* the leaders keep round 3's watch stage (measurement) */
-#define MI_MEGA_LEADER_WATCH 0
-#endif
-#ifndef MI_MEGA_RESULT_AUX            /* cache policy of the result record's store: 0 = plain, the line stays in the XCD's L2 (an sc1 store drops it) */
-#define MI_MEGA_RESULT_AUX 0
-#endif
-#ifndef MI_MEGA_FOLLOW_AUX            /* ... and of the followers' loads of it: 16 = sc1, past the L1, served by the L2 */
-#define MI_MEGA_FOLLOW_AUX 16
-#endif
-#ifndef MI_MEGA_DENSE                 /* records 16 bytes apart (chunk c of block b at c * 8192 + 16 b) instead of one per 256-byte block: only 32 leader waves poll them */
-#define MI_MEGA_DENSE 0
-#endif
-#ifndef MI_MEGA_FOLLOW_SLEEP          /* units of 64 cycles between two looks of a follower at its XCD's result */
-#define MI_MEGA_FOLLOW_SLEEP 2
-#endif
-#if MI_MEGA_ASM_REDUCE
-#define MI_WMIN wmin
-#define MI_WMAX wmax
-#define MI_WSUM wsum
-#else
-#define MI_WMIN wave_min
-#define MI_WMAX wave_max
-#define MI_WSUM wave_sum
 #endif
 // The block's contribution to a grid-wide reduction = its arrival at the barrier: every wave reduces in registers and
 // leaves its row in LDS; the wave that arrives last combines the rows in wave order and stores the block's chunks
@@ -250,7 +178,7 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
   float r[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {                      // values from n_live on are known to be zero (wave-uniform): not reduced
-    if (k < n_live) r[k] = op[k] == 0 ? MI_WMIN(v[k]) : (op[k] == 1 ? MI_WMAX(v[k]) : MI_WSUM(v[k]));
+    if (k < n_live) r[k] = op[k] == 0 ? wmin(v[k]) : (op[k] == 1 ? wmax(v[k]) : wsum(v[k]));
     else r[k] = 0.f;
   }
   unsigned before = 0;
@@ -275,12 +203,8 @@ MI_DEV void block_reduce_post(const float (&v)[NV], const int (&op)[NV], float (
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(area, 0, (int)((size_t)8 * stride * sizeof(float)), 0x00020000);
     if (lane < NCH) mine.w = tag ^ rec_hash(mine.x, mine.y, mine.z);
-#if MI_MEGA_DENSE
-    const uint32_t off = withhold || lane >= NCH ? INVALID_OFF : (uint32_t)lane * 8192u + (uint32_t)block * 16u;
-#else
     const uint32_t off = withhold ? INVALID_OFF
                                   : (lane < NCH ? (uint32_t)block * REC + 16u * lane : (lane == NCH ? (uint32_t)block * REC + 48u : INVALID_OFF));
-#endif
     __builtin_amdgcn_raw_buffer_store_b128(mine, rs, off, 0, MI_MEGA_POST_AUX);   // aux 16 = sc1: write-through, visible to the other XCDs
   }
 }
@@ -292,7 +216,6 @@ struct FoldLds {
   float mm[WAVES][4];
   float sum[WAVES][5];
   float keep[7];                          // barrier 0's totals of the speculative statistics, for barrier 1 (bounds other than (0, 1))
-  unsigned lead[4];                       // per barrier: 2 * frames passed + (this block leads its XCD at the current one)
   unsigned faulted;                       // latched by the first wave of the block whose poll budget runs out (barrier_fold: budget)
 };
 
@@ -315,104 +238,6 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
   unsigned role = 0;
   if (lane == 0) role = __hip_atomic_fetch_add(fl.ticket + bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   role = __builtin_amdgcn_readfirstlane(role) & (WAVES - 1);
-#if MI_MEGA_TWO_LEVEL
-  // ---- two levels: ONE block per XCD folds the chip's records (from memory), the other 63 take its result from the L2 ----
-  // What the finalize leaves for the next phase travels as a result record: RC chunks {3 floats, tag ^ rec_hash} in the
-  // XCD's slot.  The leader is the XCD's first block to ask (an exchange on the XCD's claim word, executed in ITS L2 - every
-  // block that touches the word shares that L2); it polls and folds exactly as every block did in round 3, so the scalars
-  // are the same bits in every XCD.  A follower polls the slot through the L2 (sc1 loads, past its CU's L1; the leader's
-  // plain store leaves the line in that very L2).  512 x fewer polls of memory: the leaders need no watch stage, and
-  // nobody's polling slows a block that is still in its phase.
-  constexpr int R_BASE = NV == 9 ? FP_LO : (NV == 1 ? FP_BMIN : FP_LO2);          // sh_fp[R_BASE, R_BASE + R_NF) ...
-  constexpr int R_NF = NV == 9 ? 15 : (NV == 1 ? 12 : 3), R_KEEP = NV == 9 ? 7 : 0; // ... then fl.keep[0, R_KEEP)
-  constexpr int RC = (R_NF + R_KEEP + 2) / 3;
-  static_assert(RC * 16 <= 256, "a result fits its slot");
-  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));                  // XCC_ID[3:0]: where this CU lives
-  float* const partials_ = ws + FP_COUNT;
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-      partials_ + (size_t)(MROW_RES + (NV == 9 ? 0 : (NV == 1 ? 1 : 2))) * a.t.part_stride, 0, 8 * 256, 0x00020000);
-  auto publish_result = [&]() {                         // the whole wave; sh_fp / fl.keep were written by its lane 0
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    float f3[3];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const int j = 3 * lane + e;
-      f3[e] = j < R_NF ? sh_fp[R_BASE + (j < R_NF ? j : 0)] : (j < R_NF + R_KEEP ? fl.keep[j < R_NF + R_KEEP ? j - R_NF : 0] : 0.f);
-    }
-    u4 mine = {__builtin_bit_cast(uint32_t, f3[0]), __builtin_bit_cast(uint32_t, f3[1]), __builtin_bit_cast(uint32_t, f3[2]), 0u};
-    mine.w = tag ^ rec_hash(mine.x, mine.y, mine.z);
-    __builtin_amdgcn_raw_buffer_store_b128(mine, rrs, lane < RC ? xcc * 256u + 16u * lane : INVALID_OFF, 0, MI_MEGA_RESULT_AUX);
-  };
-  unsigned lead = 0;
-  if (role == 0) {
-    unsigned old = tag;
-    if (lane == 0) {
-      unsigned* claim = reinterpret_cast<unsigned*>(partials_ + (size_t)MROW_CLAIM * a.t.part_stride) + ((unsigned)bar * 8u + xcc) * 16u;
-      old = __hip_atomic_exchange(claim, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    lead = __builtin_amdgcn_readfirstlane(old) != tag ? 1u : 0u;
-    if (lane == 0) __hip_atomic_store(fl.lead + bar, 2u * seq + lead, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else {
-    unsigned naps = 0, w = 0;
-    while ((int)(((w = __hip_atomic_load(fl.lead + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 1) - seq) < 0) {
-      __builtin_amdgcn_s_sleep(MI_MEGA_FLAG_SLEEP);
-      if (++naps > 64u * m.spin_limit) break;
-    }
-    lead = __builtin_amdgcn_readfirstlane(w) & 1u;
-  }
-  if (!lead) {
-    if (role == 0) {
-      const unsigned budget_f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&fl.faulted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                                    ? 1u : m.spin_limit;
-      const uint32_t off = lane < RC ? xcc * 256u + 16u * lane : INVALID_OFF;
-      uint32_t rx = 0u, ry = 0u, rz = 0u;
-      unsigned spins_f = 0;
-      for (;;) {
-        // (sc1 loads: they bypass this CU's L1 - which no other CU's store ever refreshes: an sc0 load is served by it like a
-        // plain one and never saw the result - and are served by the XCD's L2, where the leader's plain store has left the line)
-        const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, MI_MEGA_FOLLOW_AUX);
-        rx = t.x; ry = t.y; rz = t.z;
-        const bool ok = lane >= RC || (t.w ^ rec_hash(t.x, t.y, t.z)) == tag;
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-        if (++spins_f >= budget_f) {
-          if (lane == 0) {
-            __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + FP_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (m.mailbox) __hip_atomic_store(m.mailbox, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&fl.faulted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          break;
-        }
-        __builtin_amdgcn_s_sleep(MI_MEGA_FOLLOW_SLEEP);
-      }
-      if (stamps && lane == 0) stamps[0] = MI_STAMP_NOW();
-      if (lane < RC) {
-        const uint32_t w3[3] = {rx, ry, rz};
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          const int j = 3 * lane + e;
-          const float x = __builtin_bit_cast(float, w3[e]);
-          if (j < R_NF) sh_fp[R_BASE + j] = x;
-          else if (j < R_NF + R_KEEP) fl.keep[j - R_NF] = x;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (blockIdx.x == 0 && lane < RC) {                 // block 0 leaves the frame's scalars in FrameParams
-#pragma unroll
-        for (int e = 0; e < 3; ++e) if (3 * lane + e < R_NF) ws[R_BASE + 3 * lane + e] = sh_fp[R_BASE + 3 * lane + e];
-      }
-      if (stamps && lane == 0) stamps[2] = MI_STAMP_NOW();
-      if (lane == 0) __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-      unsigned naps = 0;
-      while ((int)(__hip_atomic_load(fl.flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) {
-        __builtin_amdgcn_s_sleep(MI_MEGA_FLAG_SLEEP);
-        if (++naps > 64u * m.spin_limit) break;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return;
-  }
-#endif
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(area), 0, (int)((size_t)8 * a.t.part_stride * sizeof(float)), 0x00020000);
   u4 v[2][NCH];
@@ -444,11 +269,7 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-#if MI_MEGA_DENSE
-        const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)c * 8192u + (uint32_t)((int)role * 128 + u * 64 + lane) * 16u;
-#else
         const uint32_t off = have[u][c] ? INVALID_OFF : (uint32_t)((int)role * 128 + u * 64 + lane) * REC + 16u * c;
-#endif
         const u4 t = __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, AUX);
         v[u][c] = have[u][c] ? v[u][c] : t;
       }
@@ -463,22 +284,13 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     return __builtin_amdgcn_ballot_w64(!all);
   };
   unsigned long long missing = ~0ull;
-#if MI_MEGA_EAGER_ROUND
-  // Measurement (off): one full round straight after the wave's own post, so that the waves that arrive LAST - which find
-  // every record there - are through after one round trip instead of their watch stage + L2 round + write-through round.
-  // 47.0 us per frame against 44.2: the early waves' extra round (2048 waves x 128 records while half the chip is still in
-  // its phase) costs far more than the late ones save - what the watch stage is there to prevent.
-  if (budget > 1) missing = round(std::integral_constant<int, MI_MEGA_POLL_AUX>{});
-  if (missing != 0) {
-#endif
   // Stage 0: watch TWO typical records (lanes 0 and 1: the last block of the first half of the grid and the third last
   // block) until both are there - by then nine blocks in ten have posted.  2048 waves polling all records while most
   // blocks are still in their phase slow those down (their loads and posts queue behind the polls: posts took up to
   // 4.6 us instead of 1); two requests per wave and round do not.  Four polls in flight, a new one every 512 cycles.
   // Whichever blocks post last are deliberately NOT waited for here: stage 1 asks for whatever is still missing every
   // round, so a straggler's record is seen one round trip after it lands.
-  bool waited = false;                                // (wave-uniform)
-  if (budget > 1 && !(MI_MEGA_TWO_LEVEL && !MI_MEGA_LEADER_WATCH)) {   // (a budget of 1 - the fault test - polls at once; 32 leader waves need no watch)
+  if (budget > 1) {                                   // (a budget of 1 - the fault test - polls at once)
     const int watch = lane == 0 ? a.n_blocks / 2 - 1 : a.n_blocks - 3;
     const uint32_t off = lane < 2 && watch >= 0 ? (uint32_t)watch * REC + BEACON_OFF : INVALID_OFF;
     const bool idle = !(lane < 2 && watch >= 0);
@@ -491,7 +303,6 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     uint32_t q3 = ask();
     for (;;) {
       if (there(q0)) break;
-      waited = true;
       nap(); q0 = ask();
       if (there(q1)) break;
       nap(); q1 = ask();
@@ -502,13 +313,10 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
       if ((spins += 4) > budget) break;         // stage 1 raises the error
     }
   }
-  // (Measurement, off: a wave that found both watched records at its first look - a late arrival - skipping the L2 round,
-  // on the theory that what its XCD's L2 holds of the records is mostly stale: 44.02 us per frame against 43.83.  The L2
-  // round pays for the late waves too.)
-  missing = m.l2_first && budget > 1 && (waited || !MI_MEGA_LATE_SKIPS_L2) ? round(std::integral_constant<int, 1>{}) : ~0ull;
-#if MI_MEGA_EAGER_ROUND
-  }
-#endif
+  // (Measured and taken out: a wave that found both watched records at its first look - a late arrival - skipping the L2
+  // round, on the theory that what its XCD's L2 holds of the records is mostly stale: 44.02 us per frame against 43.83.
+  // The L2 round pays for the late waves too.)
+  missing = m.l2_first && budget > 1 ? round(std::integral_constant<int, 1>{}) : ~0ull;
   while (missing != 0) {
     // The budget is checked BEFORE a round.  A budget of 1 (tests/: mi_isp_whole_frame_set_poll_limit(1)) therefore means
     // "one round, straight after the wave's own post, no watch stage": the first block to arrive cannot find the others'
@@ -554,13 +362,13 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
     }
   }
 #pragma unroll
-  for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? MI_WMAX(mm[k]) : MI_WMIN(mm[k]);
-  if (NV == 1) sum[0] = MI_WSUM(sum[0]);
+  for (int k = 0; k < NMM; ++k) mm[k] = (k & 1) ? wmax(mm[k]) : wmin(mm[k]);
+  if (NV == 1) sum[0] = wsum(sum[0]);
   if (NV >= 7) {
-    sum[0] = MI_WSUM(sum[0]); sum[1] = MI_WSUM(sum[1]);
+    sum[0] = wsum(sum[0]); sum[1] = wsum(sum[1]);
     if (rgb_sums) {                                    // else they are zero
 #pragma unroll
-      for (int k = 2; k < 5; ++k) sum[k] = MI_WSUM(sum[k]);
+      for (int k = 2; k < 5; ++k) sum[k] = wsum(sum[k]);
     }
   }
   unsigned finished = 0;
@@ -621,18 +429,12 @@ MI_DEV void barrier_fold(const MArgs& m, float* ws, unsigned seq, int bar, const
         ew::finalize_scalars_fast(FIN, fa, tot);
       }
       if (stamps) stamps[2] = MI_STAMP_NOW();
-#if !MI_MEGA_TWO_LEVEL
       __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
       // block 0 leaves the frame's scalars in FrameParams, as the multi-pass chain does (callers may read them back)
       if (blockIdx.x == 0) {
         for (int i = 0; i <= FP_MAXOUT; ++i) ws[i] = sh_fp[i];
       }
     }
-#if MI_MEGA_TWO_LEVEL
-    publish_result();                                  // first the XCD's 63 other blocks, then this block's own waves
-    if (lane == 0) __hip_atomic_store(fl.flag + bar, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
   } else {
     unsigned naps = 0;
     while ((int)(__hip_atomic_load(fl.flag + bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) {
@@ -693,21 +495,12 @@ template <class T, int N> MI_DEV void fresh(T (&x)[N]) {
 // therefore swap priority every row of phases A, B and C: `turn` counts rows, `younger` is the block's half; whoever has
 // the turn wins the ties.  46.9 -> 44.8 us per frame (a turn per row PAIR of phase A: 46.0; none in phase C: + 1.1; two
 // turns per row - one for the demosaic, one for the rest - 46.9: worse than none); with a turn per pair the halves ended
-// phase A 0.7 us apart (3.8 before).  Also measured: slices of the CU's clock instead of turns (MI_MEGA_PRIO 3: 46.0 with
-// 8192-cycle slices, 46.4 with 2048, 47.8 with 32768), the younger block always first (MI_MEGA_PRIO 2: the asymmetry
-// flips), priority level 3 instead of 1 (the same), turns in phase D (nothing).
+// phase A 0.7 us apart (3.8 before).  Also measured: slices of the CU's clock instead of turns (46.0 with 8192-cycle
+// slices, 46.4 with 2048, 47.8 with 32768), the younger block always first (the asymmetry flips), priority level 3
+// instead of 1 (the same), turns in phase D (nothing).
 MI_DEV void prio_turn(int turn, bool younger) {
-#if MI_MEGA_PRIO == 1
-  if ((((turn >> MI_MEGA_PRIO_TURN_SHIFT) & 1) != 0) == younger) asm volatile("s_setprio %0" :: "i"(MI_MEGA_PRIO_LEVEL));
+  if (((turn & 1) != 0) == younger) asm volatile("s_setprio 1");
   else asm volatile("s_setprio 0");
-#elif MI_MEGA_PRIO == 2              /* measurement: the younger block always wins */
-  if (younger) asm volatile("s_setprio 3");
-  else asm volatile("s_setprio 0");
-#elif MI_MEGA_PRIO == 3              /* time slices of the CU's own clock: both waves of a SIMD read the same counter */
-  const unsigned now = (unsigned)__builtin_readcyclecounter();
-  if ((((now >> MI_MEGA_PRIO_SHIFT) & 1u) != 0) == younger) asm volatile("s_setprio 3");
-  else asm volatile("s_setprio 0");
-#endif
 }
 
 // bounds of a packed f16 row: four values per instruction (gfx950: v_pk_minimum3_f16 / v_pk_maximum3_f16; the values are
@@ -724,9 +517,6 @@ MI_DEV float pk_hi(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return
 
 // where phase D issues the first loads of the NEXT frame of the batch: behind resident row PREFETCH_AT (registers have
 // come free by then: 24 VGPRs per retired register row)
-#ifndef MI_MEGA_D_ORDER
-#define MI_MEGA_D_ORDER 1
-#endif
 
 #ifndef MI_MEGA_PREFETCH_AT
 #define MI_MEGA_PREFETCH_AT 3            /* register rows first: behind LDS row 3 */
@@ -739,36 +529,10 @@ MI_DEV float pk_hi(uint32_t v) { half_t h[2]; __builtin_memcpy(h, &v, 4); return
 #ifndef MI_MEGA_ST_AUX
 #define MI_MEGA_ST_AUX ST_STREAM
 #endif
-#ifndef MI_MEGA_D_STAGGER
-#define MI_MEGA_D_STAGGER 0
-#endif
-#ifndef MI_MEGA_PRIO_A_BIAS
-#define MI_MEGA_PRIO_A_BIAS 0
-#endif
-#ifndef MI_MEGA_PRIO_RESET_C
-#define MI_MEGA_PRIO_RESET_C 0
-#endif
-#ifndef MI_MEGA_LOG_PER_PIXEL
-#define MI_MEGA_LOG_PER_PIXEL 0
-#endif
 // LDS rows whose second Reinhard evaluation (it needs nothing from barrier 2) runs between a wave's post and its first
 // poll of that barrier, i.e. inside the wait for the slowest block
 #ifndef MI_MEGA_PRE2
 #define MI_MEGA_PRE2 1
-#endif
-// rgb_gray of the resident pixels computed while the wave waits at barrier 0 (frames with bounds (0, 1), color_adapt == 0)
-#ifndef MI_MEGA_GRAY_PRE                /* measured: only two rows' worth fits the registers, and those buy nothing (44.46 against 44.36 us) */
-#define MI_MEGA_GRAY_PRE 0
-#endif
-#ifndef MI_MEGA_TONE_NP                 /* pixels of a row whose Reinhard chains run in lockstep (tone_row); 1 = the compiler's order.  Measured, unit /
-                                           non-unit frames: 1: 44.30 / 51.66, 2: 44.44 / 52.40, 4: 44.19 / 51.99 us - nothing (see tone_row) */
-#define MI_MEGA_TONE_NP 1
-#endif
-#ifndef MI_MEGA_GRAY_LO                /* the resident rows [LO, HI) whose gray is computed ahead: the registers decide */
-#define MI_MEGA_GRAY_LO 0
-#endif
-#ifndef MI_MEGA_GRAY_HI
-#define MI_MEGA_GRAY_HI 2
 #endif
 
 // RGB: color_adapt != 0 (per-channel sums in the statistics).  Two kernels instead of a run-time flag: with both kinds of
@@ -791,7 +555,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   __shared__ float sh_fp[FP_COUNT];
   __shared__ unsigned arrived;
   __shared__ FoldLds fl;
-  if (threadIdx.x < 4) { fl.ticket[threadIdx.x] = 0; fl.done[threadIdx.x] = 0; fl.flag[threadIdx.x] = 0; fl.lead[threadIdx.x] = 0; }
+  if (threadIdx.x < 4) { fl.ticket[threadIdx.x] = 0; fl.done[threadIdx.x] = 0; fl.flag[threadIdx.x] = 0; }
   if (threadIdx.x == 0) { arrived = 0; fl.faulted = 0; }
   if (threadIdx.x < FP_COUNT) sh_fp[threadIdx.x] = 0.f;
 
@@ -809,11 +573,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     Geo G;
     G.lane = tid & 63;
     G.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef MI_MEGA_TEST_PERMUTE          /* measurement only: even dispatch indices take the top half of the image, odd ones the bottom */
-    G.g = ((bid & 1) * (a.n_blocks >> 1) + (bid >> 1)) * WAVES + G.wave;
-#else
     G.g = bid * WAVES + G.wave;
-#endif
     G.wave_ok = G.g < a.n_waves;
     const int by = G.g / a.bands_x;
     G.bx = G.g - by * a.bands_x;
@@ -852,9 +612,7 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       load_row(G, rs, G.r_begin + 3 + 2 * j, raw[j][1]);
     }
   };
-#ifndef MI_MEGA_NOPREFETCH
   first_loads(geo(threadIdx.x, blockIdx.x), mb.io[0].src);
-#endif
 
   // ---- once per launch: the decode table ----
   for (int e = threadIdx.x; e < 4096; e += THREADS) lut[e] = tile::decode_scaled<E>((uint32_t)e, p.k_decode);
@@ -882,9 +640,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   const int unit_bytes = osz == 1 ? 8 : 16, units_per_lane = 24 * osz / unit_bytes;
   const uint32_t out_pitch = (uint32_t)p.W * 3u * (uint32_t)osz, band_base = (uint32_t)bx * BAND * 3u * (uint32_t)osz;
   const FrameIO io = mb.io[f];
-#ifdef MI_MEGA_NOPREFETCH
-  first_loads(G, io.src);
-#endif
   const unsigned seq = (unsigned)f + 1u;              // what the LDS flags of this frame's barriers count up to
   float* const ws = io.ws;
   float* const partials = ws + FP_COUNT;
@@ -924,9 +679,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   static_for<0, ROWS / 2>([&](auto ibc) {
     constexpr int IB = decltype(ibc)::value, PH = IB % 3;
     const int r = r_begin + 2 * IB;
-#if !MI_MEGA_PRIO_ROWS
-    prio_turn(IB, younger);
-#endif
     decode_row(raw[IB % 2][0], lut, lane, win[(2 * PH + 4) % 6]);
     decode_row(raw[IB % 2][1], lut, lane, win[(2 * PH + 5) % 6]);
     if constexpr (IB + 2 < ROWS / 2) {
@@ -945,17 +697,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       static_for<0, 2>([&](auto ic) {
         constexpr int I = decltype(ic)::value, RR = 2 * IB + I;
         const int row = r + I;
-#if MI_MEGA_PRIO_ROWS == 1           /* a turn per row instead of per row pair: 45.7 -> 44.9 us per frame */
-        if constexpr (RR < MI_MEGA_PRIO_A_BIAS) prio_turn(0, younger);   // (the older block's waves catch up first)
-        else prio_turn(RR, younger);
-#elif MI_MEGA_PRIO_ROWS == 2         /* two turns per row */
-        prio_turn(2 * RR, younger);
-#endif
+        prio_turn(RR, younger);
         float v[24];
         accumulate_row<PR, PC, I, true>(w6, wq, v);
-#if MI_MEGA_PRIO_ROWS == 2
-        prio_turn(2 * RR + 1, younger);
-#endif
         if (MI_CENSUS(row < 2 || row >= p.H - 2, false)) border_fix_rows<PR, PC, I>(v, tile::inside_mask(row, p.H), is_left, is_right);
         else if (MI_CENSUS(any_left || any_right, false)) border_fix_cols<PR, PC, I>(v, is_left, is_right, any_left, any_right);
         if (MI_CENSUS(p.has_ccm, false)) {            // bayer.py:152-153, sequential fp32 dot
@@ -979,16 +723,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
           unpack_row(pk, t);
           st.add8<true>(t);
         } else {
-#if MI_MEGA_LOG_PER_PIXEL              /* (one logarithm per pixel: 45.0 us per frame against 44.x) */
-          static_for<0, 4>([&](auto kc) {
-            constexpr int K = 2 * decltype(kc)::value;
-            st.add2_gray(gray_pk<K>(pk, gw0, gw1, gw2), gray_pk<K + 1>(pk, gw0, gw1, gw2));
-          });
-#else
           float g8[8];
           static_for<0, 8>([&](auto kc) { constexpr int K = decltype(kc)::value; g8[K] = gray_pk<K>(pk, gw0, gw1, gw2); });
           st.add8_gray(g8);
-#endif
         }
         // the pixels stay on the chip
         if constexpr (RR < NL) {
@@ -1039,28 +776,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     unpack_row(pk, t);
   };
 
-  // Between the post and the first poll of barrier 0 (the median wave waits ~5 us there, the last one ~2.5): rgb_gray of
-  // every resident pixel, for phase C - which is bound by VALU issue - under the assumption that the bounds will turn out
-  // to be (0, 1) (the normalisation of tonemap.py:13 is then the identity and the gray of reinhard_func, tonemap.py:120, is
-  // that of the stored pixel).  96 registers that nobody else wants while the wave waits; frames with other bounds
-  // ignore them.  Straight from the packed halves (gray_pk: three v_fma_mix_f32, fma roundings); phase D's second
-  // evaluation of the LDS rows derives it the same way, so the bounds phase C finds are those of the values phase D emits.
-#if MI_MEGA_GRAY_PRE
-  constexpr int GLO = MI_MEGA_GRAY_LO, GHI = MI_MEGA_GRAY_HI;
-  float gpre[GHI - GLO][8];
-  {
-    const float pw0 = vgpr(0.299f), pw1 = vgpr(0.587f), pw2 = vgpr(0.114f);
-    static_for<GLO, GHI>([&](auto rrc) {
-      constexpr int RR = decltype(rrc)::value;
-      fresh(gpre[RR - GLO]);
-      if (r_begin + RR < r_end) {
-        uint32_t pk[12];
-        resident_pk(rrc, pk);
-        static_for<0, 8>([&](auto kc) { constexpr int K = decltype(kc)::value; gpre[RR - GLO][K] = gray_pk<K>(pk, pw0, pw1, pw2); });
-      }
-    });
-  }
-#endif
   // ================================ barrier 0: bounds (tonemap.py:146) ================================
   MI_MSTAMP(2);
 #ifdef MI_STREAM_STAMPS
@@ -1073,15 +788,11 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   const bool unit = MI_CENSUS(lo_s == 0.f && inv_s == 1.f, true);
   // per-pixel operands live in VGPRs: a VALU instruction with an SGPR operand issues at half rate
   const float lo = vgpr(lo_s), inv = vgpr(inv_s);
-  // the normalisation of tonemap.py:13 for phases C and D as ONE fma: (x - lo) * inv = x * inv - lo * inv (two roundings
-  // instead of two, in another order: ~1e-7 relative, three orders below the f16 output's ulp); only frames whose bounds
-  // are not (0, 1) come here
-  const float nrm_c = vgpr(-lo_s * inv_s);
-#if MI_MEGA_NORM_FMA
-  auto norm_fma = [&](float x) __attribute__((always_inline)) { return clamp01(__builtin_fmaf(x, inv, nrm_c)); };
-#else
-  auto norm_fma = [&](float x) __attribute__((always_inline)) { (void)nrm_c; return norm01(x, lo, inv); };
-#endif
+  // the normalisation of tonemap.py:13 in phases C and D; only frames whose bounds are not (0, 1) come here.  (As ONE fma,
+  // x * inv - lo * inv, measured on one box, unit / non-unit frames: 44.05 / 50.13 us with it, 43.81 / 50.90 without - the
+  // frames it is not executed for pay 0.24 us for the other arm's different register allocation.  Not taken: the headline
+  // is the unit frame.)
+  auto norm_fma = [&](float x) __attribute__((always_inline)) { return norm01(x, lo, inv); };
   if (!unit) {
     // ============================ phase B: the statistics for bounds other than (0, 1) ============================
     // Only the sum of log(gray) needs the pixels again; the other statistics of the normalised image follow from the
@@ -1094,14 +805,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       if (r_begin + RR < r_end) {
         uint32_t pk[12];
         resident_pk(rrc, pk);
-#if MI_MEGA_LOG_PER_PIXEL
-        static_for<0, 4>([&](auto kc) {
-          constexpr int K = 2 * decltype(kc)::value;
-          const float ga = (gray_pk<K>(pk, gw0, gw1, gw2) - lo) * inv, gb = (gray_pk<K + 1>(pk, gw0, gw1, gw2) - lo) * inv;
-          sl0 += hw_log2(fmaxf(ga, 1e-4f));
-          sl1 += hw_log2(fmaxf(gb, 1e-4f));
-        });
-#else
         // one logarithm per row: the product of its eight clamped gray values (Stats2::add8_gray).  The normalised gray in
         // three instructions: (gray(x) - lo) * inv = (w0 inv) r + (w1 inv) g + (w2 inv) b - lo inv, the constant as the first
         // fma's addend (differs from subtract-then-multiply by ~1e-7 relative; the scalars' contract is 1e-4)
@@ -1113,7 +816,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
           c[K] = fmaxf(fma_mix_h<e + 2>(pk[(e + 2) / 2], gwi2, a1), 1e-4f);
         });
         sl0 += hw_log2(((c[0] * c[1]) * (c[2] * c[3])) * ((c[4] * c[5]) * (c[6] * c[7])));
-#endif
       }
     });
     const float v1[1] = {col_ok ? sl0 + sl1 : 0.f};
@@ -1139,109 +841,23 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   // identity; CA0: color_adapt == 0, one pow per pixel.  The variant is chosen ONCE per phase, outside the row loops: the
   // executed code of a phase is then one contiguous stretch (the instruction cache is shared by two CUs and a wave's
   // straight-line code is ~100 KB; interleaved dead variants cost misses).
-  // g8: rgb_gray of the row's pixels when it is known already (UNIT && CA0 only: the pixel IS the normalised pixel)
-  auto adapt_g = [&](float g) __attribute__((always_inline)) {     // reinhard_adapt_ca0 from the gray (tonemap.py:121-129)
-    const float am = rk.mean3[0] + rk.la * (g - rk.mean3[0]);
-    return hw_pow(rk.ei * am, rk.map_key);
-  };
-  // color_adapt == 0: NP pixels of a row in LOCKSTEP, one dependent step of each per stage, the stages pinned by
-  // scheduling barriers.  Left to itself the compiler - short of registers here - emits one pixel after the other, each a
-  // chain of ~15 dependent instructions (mul fmac fmac sub fma mul log [s_nop] mul exp [s_nop] add rcp [s_nop] mul: the
-  // round-3 census of phase C): a dependent VALU instruction issues 7.4 cycles after its producer, so a wave got an issue
-  // slot every ~7 cycles where two waves of independent work get one every 2.3 each, and every transcendental's consumer
-  // waited out its hazard in an s_nop.  With NP chains side by side the next instruction of a wave is never the consumer of
-  // the previous one (census: the 146 s_nop of phase C are gone).  MEASURED: no gain (MI_MEGA_TONE_NP) - with two waves per
-  // SIMD the other wave already filled the slots a chain leaves open; phase C's ~10 us are its instruction count (440
-  // transcendentals at 7.4 cycles, ~610 single-rate and ~1260 double-rate instructions per wave), not its order.  Off.
-  // The arithmetic, its order and its roundings are those of reinhard_adapt_ca0 / reinhard_map
-  // (isp_math.h: gray = fma(b, .114, fma(r, .299, g * .587)), am = fma(la, gray - mean, mean), ad = exp2(map_key *
-  // log2(ei * am)), q = x * rcp(ad + x)).
-#define MI_SB() __builtin_amdgcn_sched_barrier(0)
-  auto adapt_np = [&](auto np_c, const float (*x)[3], float* ad) __attribute__((always_inline)) {
-    constexpr int NP = decltype(np_c)::value;
-    float g[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = x[p][1] * 0.587f;
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = __builtin_fmaf(x[p][0], 0.299f, g[p]);
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = __builtin_fmaf(x[p][2], 0.114f, g[p]);
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = g[p] - rk.mean3[0];
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = __builtin_fmaf(rk.la, g[p], rk.mean3[0]);
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = rk.ei * g[p];
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = hw_log2(g[p]);
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) g[p] = rk.map_key * g[p];
-    MI_SB();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) ad[p] = hw_exp2(g[p]);
-    MI_SB();
-  };
-  auto tone_row = [&](auto unit_c, auto ca0_c, const float (&t)[24], float (&q)[24], const float* g8 = nullptr) {
+  // (Measured and taken out, round 4 - profiles/r04_barrier_and_phaseC_experiments.txt: the Reinhard chains of 2 or 4
+  // pixels in LOCKSTEP, stage by stage between scheduling barriers.  The 146 hazard s_nop of phase C went, the time did
+  // not: 44.19 - 44.44 against 44.30 us per frame - with two waves per SIMD the other wave already fills the slots a
+  // dependent chain leaves open; phase C's ~10 us are its instruction count (440 transcendentals at 7.4 cycles, ~610
+  // single-rate and ~1260 double-rate instructions per wave), not its order.  Likewise the gray of the resident pixels
+  // computed ahead, in barrier 0's wait: two rows' worth fit the registers, nothing measurable.)
+  auto tone_row = [&](auto unit_c, auto ca0_c, const float (&t)[24], float (&q)[24]) {
     constexpr bool UNIT = decltype(unit_c)::value, CA0 = decltype(ca0_c)::value;
-    if constexpr (CA0 && MI_MEGA_TONE_NP > 1 && !MI_MEGA_GRAY_PRE) {
-      constexpr int NP = MI_MEGA_TONE_NP;
-      static_for<0, 8 / NP>([&](auto gc) {
-        constexpr int P0 = decltype(gc)::value * NP;
-        float x[NP][3], ad[NP], r[NP][3];
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) x[p][ch] = UNIT ? t[3 * (P0 + p) + ch] : norm_fma(t[3 * (P0 + p) + ch]);
-        MI_SB();
-        adapt_np(std::integral_constant<int, NP>{}, x, ad);
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) r[p][ch] = ad[p] + x[p][ch];
-        MI_SB();
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) r[p][ch] = hw_rcp(r[p][ch]);
-        MI_SB();
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) q[3 * (P0 + p) + ch] = x[p][ch] * r[p][ch];
-        MI_SB();
-      });
-      return;
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float x[3], o[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm_fma(t[3 * k + ch]);
-      if constexpr (UNIT && CA0 && MI_MEGA_GRAY_PRE) {
-        const float ad = adapt_g(g8[k]);
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) o[ch] = reinhard_map(x[ch], ad);
-      } else {
-        reinhard_px<CA0>(x, rk, o);
-      }
+      reinhard_px<CA0>(x, rk, o);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) q[3 * k + ch] = o[ch];
     }
-  };
-  // a resident row as fp32 values and (unit bounds, color_adapt == 0) its gray, from the packed halves
-  auto resident_g = [&](auto rrc, float (&t)[24], float (&g8)[8]) {
-    uint32_t pk[12];
-    resident_pk(rrc, pk);
-    const float pw0 = vgpr(0.299f), pw1 = vgpr(0.587f), pw2 = vgpr(0.114f);
-    static_for<0, 8>([&](auto kc) { constexpr int K = decltype(kc)::value; g8[K] = gray_pk<K>(pk, pw0, pw1, pw2); });
-    unpack_row(pk, t);
   };
   auto dispatch = [&](auto&& phase) {
     if (ca0) {
@@ -1263,44 +879,14 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   // mapped value are those of its smallest and largest channel: two reciprocals per pixel instead of three (the value
   // is the same instruction sequence on the same operand; where the hardware reciprocal is not monotone to the last
   // bit the bound can differ from the three-channel one by an ulp - the scalars' contract is 1e-4).
-  auto tone_bounds_row = [&](auto unit_c, const float (&t)[24], const float* g8 = nullptr) {
+  auto tone_bounds_row = [&](auto unit_c, const float (&t)[24]) {
     constexpr bool UNIT = decltype(unit_c)::value;
-    if constexpr (MI_MEGA_TONE_NP > 1 && !MI_MEGA_GRAY_PRE) {
-      constexpr int NP = MI_MEGA_TONE_NP;
-      static_for<0, 8 / NP>([&](auto gc) {
-        constexpr int P0 = decltype(gc)::value * NP;
-        float x[NP][3], ad[NP], lo_[NP], hi_[NP], rl[NP], rh[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) x[p][ch] = UNIT ? t[3 * (P0 + p) + ch] : norm_fma(t[3 * (P0 + p) + ch]);
-        MI_SB();
-        adapt_np(std::integral_constant<int, NP>{}, x, ad);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { lo_[p] = fminf(x[p][0], fminf(x[p][1], x[p][2])); hi_[p] = fmaxf(x[p][0], fmaxf(x[p][1], x[p][2])); }
-        MI_SB();
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { rl[p] = ad[p] + lo_[p]; rh[p] = ad[p] + hi_[p]; }
-        MI_SB();
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { rl[p] = hw_rcp(rl[p]); rh[p] = hw_rcp(rh[p]); }
-        MI_SB();
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { rl[p] = lo_[p] * rl[p]; rh[p] = hi_[p] * rh[p]; }
-        MI_SB();
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { vmin = fminf(vmin, rl[p]); vmax = fmaxf(vmax, rh[p]); }
-      });
-      return;
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float x[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) x[ch] = UNIT ? t[3 * k + ch] : norm_fma(t[3 * k + ch]);
-      float ad;                                         // (the very function phase D evaluates again)
-      if constexpr (UNIT && MI_MEGA_GRAY_PRE) ad = adapt_g(g8[k]);
-      else ad = reinhard_adapt_ca0(x, rk);
+      const float ad = reinhard_adapt_ca0(x, rk);         // (the very function phase D evaluates again)
       const float xmin = fminf(x[0], fminf(x[1], x[2])), xmax = fmaxf(x[0], fmaxf(x[1], x[2]));
       vmin = fminf(vmin, reinhard_map(xmin, ad));
       vmax = fmaxf(vmax, reinhard_map(xmax, ad));
@@ -1309,28 +895,16 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
     if constexpr (RR >= NL) fresh(qr_[RR - NL]);
-    prio_turn(RR >> MI_MEGA_PRIO_C_SHIFT, younger);
+    prio_turn(RR, younger);
     if (r_begin + RR < r_end) {
       float t[24];
       resident(rrc, t);
-#if MI_MEGA_GRAY_PRE
-      // (rows outside [GLO, GHI): the gray from the unpacked pixel, mul / fma / fma as gray_pk rounds it)
-      float g8_[8];
-      const float* g8 = g8_;
-      if constexpr (RR >= GLO && RR < GHI) g8 = gpre[RR - GLO];
-      else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) g8_[k] = __builtin_fmaf(t[3 * k + 2], 0.114f, __builtin_fmaf(t[3 * k + 1], 0.587f, t[3 * k] * 0.299f));
-      }
-#else
-      const float* g8 = nullptr;
-#endif
       if (RR < NL && ca0) {                            // (wave-uniform)
-        if (unit) tone_bounds_row(std::true_type{}, t, g8);
+        if (unit) tone_bounds_row(std::true_type{}, t);
         else tone_bounds_row(std::false_type{}, t);
       } else {
         float q[24];
-        dispatch([&](auto unit_c, auto ca0_c) { tone_row(unit_c, ca0_c, t, q, g8); });
+        dispatch([&](auto unit_c, auto ca0_c) { tone_row(unit_c, ca0_c, t, q); });
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           vmin = fminf(vmin, fminf(q[3 * k], fminf(q[3 * k + 1], q[3 * k + 2])));
@@ -1347,13 +921,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   // From here to the first row of the next frame the waves keep the priority of phase C's last turn: the younger block's
   // waves 1, the older one's 0.  Measured per frame: as is 44.4 us; both at 0 (the older wave wins the ties of phase D)
   // 45.18; both at 1: 44.89; the younger one's at 3: 44.50; turns per row in phase D 45.02.
-#if MI_MEGA_PRIO_RESET_C == 1        /* measurement: both waves at priority 0 from the end of phase C on */
-  asm volatile("s_setprio 0");
-#elif MI_MEGA_PRIO_RESET_C == 2      /* measurement: the younger block's waves at priority 3 */
-  if (younger) asm volatile("s_setprio 3"); else asm volatile("s_setprio 0");
-#elif MI_MEGA_PRIO_RESET_C == 3      /* measurement: both at priority 1 */
-  asm volatile("s_setprio 1");
-#endif
   {
     if (!col_ok) { vmin = __builtin_inff(); vmax = -__builtin_inff(); }
     const float v2[2] = {vmin, vmax};
@@ -1370,10 +937,9 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
     static_for<0, PRE2>([&](auto rrc) {
       constexpr int RR = decltype(rrc)::value;
       if (r_begin + RR < r_end) {
-        float t[24], g8[8];
-        if constexpr (decltype(unit_c)::value && decltype(ca0_c)::value && MI_MEGA_GRAY_PRE) resident_g(rrc, t, g8);
-        else resident(rrc, t);
-        tone_row(unit_c, ca0_c, t, qpre[RR], g8);
+        float t[24];
+        resident(rrc, t);
+        tone_row(unit_c, ca0_c, t, qpre[RR]);
       }
     });
   });
@@ -1385,17 +951,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
   MI_MSTAMP(7);
   const float lo2 = vgpr(sh_fp[FP_LO2]), inv2 = vgpr(sh_fp[FP_INV2]);
   const float out_scale = vgpr(p.out_scale);
-#if MI_MEGA_D_STAGGER > 0
-  // Measurement: the older block's waves let the younger one's store first (phase D is bound by the chip's write rate:
-  // whoever stores first is done first and goes on to the next frame's phase A - arithmetic - while the other half's rows
-  // drain; MI_MEGA_PRIO_A_BIAS then gives the late half the priority in the first rows of phase A).  Per frame, naps of
-  // 1024 cycles / biased rows: 2 / 0 44.79, 2 / 6 45.21, 4 / 0 44.66, 4 / 6 44.89, 6 / 0 44.55, 6 / 6 44.43, 10 / 6 45.05,
-  // 10 / 12 44.72, 14 / 8 45.99 us against 44.4 without: a wave alone on its SIMD does not make up for the wait.
-  if (!younger) {
-#pragma unroll 1
-    for (int z = 0; z < MI_MEGA_D_STAGGER; ++z) __builtin_amdgcn_s_sleep(16);
-  }
-#endif
 
   // ================================ phase D: final map (tonemap.py:154) ================================
   uint32_t lane_off[6];
@@ -1409,9 +964,6 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
       io.dst, 0, (int)((uint32_t)p.H * (uint32_t)p.W * 3u * (uint32_t)osz), 0x00020000);
   auto finish_row = [&](auto rrc, float (&q)[24]) {
     constexpr int RR = decltype(rrc)::value;
-#if MI_MEGA_PRIO_D
-    prio_turn(RR, younger);
-#endif
     linear_n<24>(q, lo2, inv2, p.gamma_inv, out_scale);
     // staging: the LDS slot of a row that has been consumed (its own, or row 0's for the register rows)
     uint4* stage = xl[wave][RR < NL ? RR : 0];
@@ -1427,51 +979,32 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
         __builtin_memcpy(mine, pk, sizeof(mine));
         // Measurement variants (scripts/build_variant.sh; DESIGN.md 5.1d "what the stores cost"): 44.9 us per frame as shipped,
         // 37.5 with MI_MEGA_TEST_NOSTORE, 39.4 with ..._STAGE_ONLY, 44.8 with ..._STORE_ONLY, 54.6 / 96.1 with ..._DIRECT=0 / 2.
-#if defined(MI_MEGA_TEST_DIRECT)       /* every lane stores its own 48 bytes: no LDS transpose, 16-byte pieces 48 apart */
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          buffer_store_unit<16, MI_MEGA_TEST_DIRECT>(drsrc, &mine[j], lane < active_lanes ? (uint32_t)lane * 48u + 16u * j : INVALID_OFF, row_base);
-#elif defined(MI_MEGA_TEST_STAGE_ONLY) /* the LDS transpose and the store instructions, but no byte reaches memory */
-        {
-          const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(io.dst, 0, p.H < 0 ? 16 : 0, 0x00020000);
-          wave_store_units<uint4, 3, ST_STREAM>(none, row_base, lane_off, lane, stage, mine);
-        }
-#elif defined(MI_MEGA_TEST_STORE_ONLY) /* the same bytes to the same places, not transposed (a scrambled image) */
-#pragma unroll
-        for (int j = 0; j < 3; ++j) buffer_store_unit<16, ST_STREAM>(drsrc, &mine[j], lane_off[j], row_base);
-#elif defined(MI_MEGA_TEST_NOSTORE)    /* the image is not stored */
-        asm volatile("" :: "v"(mine[0].x), "v"(mine[1].y), "v"(mine[2].z));
-#else
         wave_store_units<uint4, 3, MI_MEGA_ST_AUX>(drsrc, row_base, lane_off, lane, stage, mine);   // streamed: nobody reads the output back
-#endif
         break;
       }
     }
   };
-  // Order (MI_MEGA_D_ORDER 1): the row(s) evaluated before the barrier, then the REGISTER rows - their mapped values are
+  // Order: the row(s) evaluated before the barrier, then the REGISTER rows - their mapped values are
   // ready, so their 7 x 3 KB of stores per wave are under way within a microsecond and the memory system is busy from
   // the start of the phase -, then Reinhard again for the other LDS rows (their mapped values had no room to stay) while
   // those stores drain.  Order 0 (round 2): LDS rows first, the burst of the register rows' stores at the end.
-  constexpr bool REGS_FIRST = MI_MEGA_D_ORDER == 1 && PRE2 >= 1;   // (row 0's slot, the register rows' staging, must be free)
+  constexpr bool REGS_FIRST = PRE2 >= 1;   // (row 0's slot, the register rows' staging, must be free)
   auto lds_rows = [&](auto regs_first_c) {
     constexpr bool REGS_FIRST = decltype(regs_first_c)::value;
     dispatch([&](auto unit_c, auto ca0_c) {
       static_for<PRE2, NL>([&](auto rrc) {
         constexpr int RR = decltype(rrc)::value;
         if (r_begin + RR < r_end) {
-          float t[24], q[24], g8[8];
-          if constexpr (decltype(unit_c)::value && decltype(ca0_c)::value && MI_MEGA_GRAY_PRE) resident_g(rrc, t, g8);
-          else resident(rrc, t);
-          tone_row(unit_c, ca0_c, t, q, g8);
+          float t[24], q[24];
+          resident(rrc, t);
+          tone_row(unit_c, ca0_c, t, q);
           finish_row(rrc, q);
         }
-#ifndef MI_MEGA_NOPREFETCH
         // the next frame's first rows are asked for while the last rows of this one are mapped and stored (unconditional -
         // the last frame asks for its own rows once more: a condition would keep the OLD contents of these 32 registers
         // alive from phase A to here, as the other arm of the merge)
         if constexpr (REGS_FIRST && RR == (MI_MEGA_PREFETCH_AT < NL - 1 ? MI_MEGA_PREFETCH_AT : NL - 1))
           first_loads(G, mb.io[f + 1 < mb.n_frames ? f + 1 : f].src);
-#endif
       });
     });
   };
@@ -1485,10 +1018,8 @@ __global__ __launch_bounds__(THREADS, 2) void frame_kernel(const MBatch mb) {
         for (int j = 0; j < 24; ++j) q[j] = qr_[RR - NL][j];
         finish_row(rrc, q);
       }
-#ifndef MI_MEGA_NOPREFETCH
       if constexpr (!REGS_FIRST && RR == (MI_MEGA_PREFETCH_AT_LATE < ROWS - 1 ? MI_MEGA_PREFETCH_AT_LATE : ROWS - 1))
         first_loads(G, mb.io[f + 1 < mb.n_frames ? f + 1 : f].src);
-#endif
     });
   };
   static_for<0, PRE2>([&](auto rrc) {
