@@ -339,6 +339,21 @@ def other_workloads(frames, host, device, frames_per_step):
     runs = [timed(step6k, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
     entry("reference_bench_6_cameras_full_resolution_batched_load_no_write_back", runs, BYTES_IN + H * W * 3, 6, 40,
           note="extensions: load_packed12_batch + tonemap_reinhard(write_back=False) (images not overwritten with p; same u8 outputs)")
+    # ... and as ONE call per step: the bench's Processor (bench/camera_isp.py:23-27) drops the loaded images, so they need
+    # not exist - ISP.process_packed12 on the camera-group kernel (csrc/isp_mega_cam.h)
+    isp6c = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, device=device)
+    def step6c():
+        isp6c.process_packed12(frames[:6], gamma=0.6)
+    runs = [timed(step6c, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
+    entry("reference_bench_6_cameras_full_resolution_one_call", runs, BYTES_IN + H * W * 3, 6, 40,
+          note="extension: ISP.process_packed12 = tonemap_reinhard([load_packed12(f) ...]) in one call, same u8 outputs and "
+               "metering state bit for bit; the loaded images (which the reference's bench drops) are never written: "
+               "subsample from the packed frames -> metering -> one persistent launch from packed bytes to u8")
+    def step6ck():
+        isp6c.process_packed12(frames[:6], gamma=0.6, keep_images=True)
+    runs = [timed(step6ck, 40, 3, device) / (40 * 6) * 1e6 for _ in range(3)]
+    entry("reference_bench_6_cameras_full_resolution_one_call_images_kept", runs, BYTES_IN + H * W * 3 + H * W * 6, 6, 40,
+          note="the same with keep_images=True: the images the reference leaves behind (p, camera_isp.py:211) are stored too")
     return res
 
 

@@ -232,6 +232,35 @@ int mi_isp_camera_frame_batch(const uint8_t* const* packed_host, void* const* im
                               float alpha, int tonemap, float gamma, float intensity, float light_adapt,
                               float color_adapt, int transform, void* ws_dev, void* stream);
 
+/* One FULL-RESOLUTION camera group from packed bytes to u8 outputs without the image in between - what the reference's
+ * bench does per step (taichi_image/bench/camera_isp.py:19-28, Processor.__call__: ISP.load_packed12 per camera,
+ * camera_isp.py:333-340; ISP.tonemap_reinhard over the list, :394-403 -> update_metering :376-385 + reinhard_kernel :177-218;
+ * the loaded images are dropped).  Three steps on `stream`: the stride-8 subsample of every camera straight from its
+ * packed frame (only the rows r % 8 == 0 are demosaiced), the rolling metering over the subsamples (mi_isp_metering), and
+ * ONE persistent launch that walks through the cameras: demosaic -> the f16 pixels resident on the chip -> Reinhard and
+ * its maximum -> grid barrier (max_out, :213) -> u8 = 255 (p / max_out)^(1 / gamma).  HBM sees the packed frame in and the
+ * u8 image out.  Same bits as mi_isp_camera_frame_batch(scale <= 0, tonemap 0, no transform) in outs, state9 and images.
+ *   packed_host / outs_host: host arrays of n device pointers (12-bit standard layout; u8 (H, W, 3), 8-byte aligned).
+ *   images_host: NULL (the bench's case: p is not stored anywhere), or n device pointers to (H, W, 3) f16 buffers
+ *     (16-byte aligned) that receive what the reference leaves in its loaded images: p, camera_isp.py:211.
+ *   state9_dev / alpha: as mi_isp_camera_frame_batch.  Metering stride 8, f16 work dtype (Camera16), 1 <= n <= 64.
+ *   scratch_dev: mi_isp_camera_group_scratch_bytes(n, H, W) bytes (the subsamples).
+ *   ws_dev: (n + 1) x mi_isp_workspace_bytes(H, W) bytes, zero-filled once (a workspace per camera + the metering's).
+ * mi_isp_camera_group_fits: 1 if the frame fits the resident grid (as mi_isp_pipeline12_whole_frame_fits) with this
+ *   pattern, work dtype (MI_F16 only) and metering stride (8 only); otherwise use mi_isp_camera_frame_batch.
+ * A grid barrier that times out (a foreign kernel holding CUs) sets the camera's workspace fault word and the device's
+ * camera-group mailbox word: mi_isp_camera_group_faults(clear) reads it (a host read, no synchronisation); the outputs of
+ * that call are invalid.  mi_isp_camera_group_set_poll_limit(polls): poll budget of later launches (0 = default; tests: 1).
+ * Launched in the one order of the library's resident-grid kernels (see mi_isp_whole_frame_set_sabotage). */
+int mi_isp_camera_group_reinhard(const uint8_t* const* packed_host, void* const* images_host, uint8_t* const* outs_host,
+                                 int n, int H, int W, int pattern, const float* ccm9_host, float* state9_dev, float alpha,
+                                 float gamma, float intensity, float light_adapt, float color_adapt, void* scratch_dev,
+                                 void* ws_dev, void* stream);
+int mi_isp_camera_group_fits(int H, int W, int pattern, int work_dtype, int metering_stride);
+size_t mi_isp_camera_group_scratch_bytes(int n, int H, int W);
+int mi_isp_camera_group_faults(int clear);
+int mi_isp_camera_group_set_poll_limit(unsigned polls);
+
 /* The same chain (test/pipeline.py:26-32) as ONE persistent launch (csrc/isp_mega.h): the frame is demosaiced once,
  * the f16 RGB image stays in registers and LDS, the three global dependencies of tonemap.py:146-154 are grid
  * barriers inside the kernel; HBM sees the packed frame in and the output out.  f16 work dtype; out_dtype u8 / u16 /

@@ -481,6 +481,68 @@ def camera_isp(name: str, dtype=types.f32):
             _written_in_place(images)
             return outputs
 
+        def process_packed12(self, frames: List[torch.Tensor], gamma: float = 1.0, intensity: float = 1.0,
+                             light_adapt: float = 1.0, color_adapt: float = 0.0, keep_images: bool = False):
+            """Extension (not in the reference): one step of the reference's own bench in one call -
+            `Processor.__call__` of bench/camera_isp.py:23-27:
+
+                images = [isp.load_packed12(f) for f in frames]
+                return isp.tonemap_reinhard(images, gamma=...)
+
+            with the same u8 outputs and the same metering state afterwards, bit for bit.  For a full-resolution
+            Camera16 group that fits the chip (`mi_isp_camera_group_fits`: 4096 x 3072 on MI355X, metering stride 8, no
+            resize, no orientation transform, single process) the loaded images never exist in memory: the metering reads
+            a subsample demosaiced straight from the packed frames, and ONE persistent launch takes every camera from
+            packed bytes to its u8 image (csrc/isp_mega_cam.h).  Everything else takes the two calls above.
+            keep_images=True returns `(outputs, images)`, the images holding what the reference leaves in them (p,
+            camera_isp.py:211); by default only the outputs are returned, as the bench's Processor does."""
+            _typecheck("frames", frames, list)
+            _typecheck("keep_images", keep_images, bool)
+            for n, v in (("gamma", gamma), ("intensity", intensity), ("light_adapt", light_adapt),
+                         ("color_adapt", color_adapt)):
+                _typecheck(n, v, float)
+            assert len(frames) > 0, "need at least one frame"
+            L = _native.lib()
+            f0 = frames[0]
+            fused = (dtype is types.f16 and self.process_group is None and self.resize_width == 0 and self.scale is None
+                     and self.transform == interpolate.ImageTransform.none and self.metering_stride == 8
+                     and 1 <= len(frames) <= 64
+                     and all(isinstance(f, torch.Tensor) and f.ndim == 2 and f.dtype == torch.uint8 and f.shape == f0.shape
+                             for f in frames)
+                     and f0.shape[1] % 3 == 0)
+            if fused:
+                h, w = f0.shape[0], f0.shape[1] * 2 // 3
+                with torch.cuda.device(self.device):
+                    fused = bool(L.mi_isp_camera_group_fits(h, w, self._demosaic_pattern.value, dtype.code, 8))
+            if not fused:
+                images = self.load_packed12_batch(frames)
+                outputs = self.tonemap_reinhard(images, gamma, intensity, light_adapt, color_adapt)
+                return (outputs, images) if keep_images else outputs
+            srcs = [f.to(self.device).contiguous() for f in frames]
+            with torch.cuda.device(self.device):
+                if L.mi_isp_metering_faults(1):
+                    raise MeteringTimeout("an earlier update_metering on this device timed out at its grid barrier: its "
+                                          "metrics were left unchanged and outputs tone-mapped with them are invalid")
+                if L.mi_isp_camera_group_faults(1):
+                    raise TonemapTimeout("an earlier process_packed12 on this device timed out waiting for an image's "
+                                         "max_out: the outputs of that call are invalid")
+            n = len(srcs)
+            outputs = [torch.empty((h, w, 3), dtype=torch.uint8, device=self.device) for _ in srcs]
+            images = [torch.empty((h, w, 3), dtype=torch_dtype, device=self.device) for _ in srcs] if keep_images else None
+            if self.metrics is None:                         # camera_isp.py:376-385
+                metrics, t = torch.zeros(9, dtype=torch.float32, device=self.device), 0.0
+            else:
+                metrics, t = self.metrics.clone(), 1.0 - self.moving_alpha
+            scratch = torch.empty(int(L.mi_isp_camera_group_scratch_bytes(n, h, w)), dtype=torch.uint8, device=self.device)
+            ws = _native.workspace(h, w, self.device, slots=n + 1)
+            _native.check(L.mi_isp_camera_group_reinhard(
+                _native.ptr_array(srcs), _native.ptr_array(images) if keep_images else None, _native.ptr_array(outputs), n,
+                h, w, self._demosaic_pattern.value, _native.ccm_arg(self.color_correct_matrix), metrics.data_ptr(),
+                float(t), float(gamma), float(intensity), float(light_adapt), float(color_adapt), scratch.data_ptr(),
+                ws.data_ptr(), _native.stream_ptr(self.device)))
+            self.metrics = metrics
+            return (outputs, images) if keep_images else outputs
+
         def tonemap_linear(self, images: List[torch.Tensor], gamma: float = 1.0):
             """camera_isp.py:405-413."""
             _typecheck("images", images, list)

@@ -8,6 +8,7 @@
 #include "isp_resize_tile.h"
 #include "isp_stream.h"
 #include "isp_mega.h"
+#include "isp_mega_cam.h"
 #include "isp_stream_resize.h"
 #include <mutex>
 #include <atomic>
@@ -751,6 +752,141 @@ extern "C" int mi_isp_camera_frame_batch(const uint8_t* const* packed, void* con
                                  transform, ws, stream);
   return mi_isp_linear_batch(const_cast<const void* const*>(images), outs, n, Hd, Wd, work_dtype, state9, gamma, transform,
                              ws, stream);
+}
+
+// ---- one camera group at full resolution: subsample, metering, ONE persistent launch (isp_mega_cam.h) -------------------
+// What the reference's bench does per step (bench/camera_isp.py:19-28: load_packed12 per camera, tonemap_reinhard over the
+// list, the loaded images dropped): the stride-8 subsample of every camera straight from its packed frame
+// (strm::sub_kernel), the rolling metering over the subsamples (mi_isp_metering: camera_isp.py:376-385 -> :142-175), then
+// mega::camera_kernel walks through the cameras - demosaic, Reinhard, max_out at a grid barrier, u8 out - with the image
+// resident on the chip.  images == NULL: p is not stored (the bench drops it); else images[i] receives what the reference
+// leaves in the loaded image (camera_isp.py:211).
+static int g_cam_per_cu[4] = {-1, -1, -1, -1};
+static unsigned g_cam_poll_limit = 0;
+
+static bool camera_group_fits(int H, int W, int pattern, strm::SArgs& a) {
+  if (pattern < 0 || pattern > 3 || H <= 0 || W <= 0) return false;
+  tile::Params p = {};
+  p.H = H; p.W = W; p.src_kind = tile::SRC_PACKED12; p.src_fast = ((int64_t)W * 3 / 2) % 4 == 0; p.in_scale = 1.f; p.vec_store = 1;
+  if (!strm::supported(p, MI_F16) || (int64_t)H * W * 6 >= (int64_t)strm::INVALID_OFF) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  std::lock_guard<std::mutex> lock(mega_mu());
+  if (g_cam_per_cu[pattern] < 0) g_cam_per_cu[pattern] = mega::cam_blocks_per_cu(pattern);
+  if (g_mega.n_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    g_mega.n_cus[dev] = n;
+  }
+  return g_cam_per_cu[pattern] >= 2 && mega::geometry(H, W, g_mega.n_cus[dev], a);
+}
+
+extern "C" int mi_isp_camera_group_fits(int H, int W, int pattern, int work_dtype, int metering_stride) {
+  strm::SArgs a = {};
+  return work_dtype == MI_F16 && metering_stride == 8 && camera_group_fits(H, W, pattern, a) ? 1 : 0;
+}
+
+extern "C" size_t mi_isp_camera_group_scratch_bytes(int n, int H, int W) {
+  if (n <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t per = (size_t)((H + 7) / 8) * (size_t)((W + 7) / 8) * 3 * sizeof(half_t);
+  return (size_t)n * ((per + 255) / 256 * 256);
+}
+
+extern "C" int mi_isp_camera_group_set_poll_limit(unsigned polls) {
+  std::lock_guard<std::mutex> lock(mega_mu());
+  g_cam_poll_limit = polls;
+  return 0;
+}
+
+extern "C" int mi_isp_camera_group_faults(int clear) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  std::lock_guard<std::mutex> lock(mega_mu());
+  ew::ResidentOrder& ord = ew::resident_order();
+  if (!ord.mailbox_host[dev]) return 0;
+  volatile unsigned* mb = ord.mailbox_host[dev] + ew::MAILBOX_CAMERA_GROUP;
+  const unsigned v = *mb;
+  if (clear) *mb = 0;
+  return (int)v;
+}
+
+extern "C" int mi_isp_camera_group_reinhard(const uint8_t* const* packed, void* const* images, uint8_t* const* outs, int n,
+                                            int H, int W, int pattern, const float* ccm9, float* state9, float alpha,
+                                            float gamma, float intensity, float light_adapt, float color_adapt,
+                                            void* scratch, void* ws, void* stream) {
+  const char* who = "camera_group_reinhard";
+  MI_REQUIRE(packed && outs && state9 && scratch && ws, "%s: null pointer", who);
+  MI_REQUIRE(n >= 1 && n <= mega::MAX_BATCH, "%s: 1 .. %d cameras per call", who, mega::MAX_BATCH);
+  MI_REQUIRE(gamma > 0.f, "%s: gamma must be positive", who);
+  hipStream_t s = (hipStream_t)stream;
+  tile::Params p = {};
+  for (int i = 0; i < n; ++i) {
+    MI_REQUIRE(packed[i] && outs[i] && (!images || images[i]), "%s: camera %d has a null buffer", who, i);
+    MI_REQUIRE(((uintptr_t)outs[i] & 7) == 0 && (!images || ((uintptr_t)images[i] & 15) == 0),
+               "%s: camera %d: outputs must be 8-byte, images 16-byte aligned", who, i);
+    tile::Params pi = {};
+    if (int rc = fill_common(pi, H, W, pattern, ccm9, who)) return rc;
+    if (int rc = packed_params(pi, packed[i], H, W, 12, 0, MI_F16, who)) return rc;
+    MI_REQUIRE(strm::supported(pi, MI_F16), "%s: camera %d: the packed frame does not take the streaming kernels "
+               "(standard 12-bit layout, W %% 8 == 0, even H, 4-byte aligned rows)", who, i);
+    if (i == 0) p = pi;
+  }
+  strm::SArgs ma = {};
+  MI_REQUIRE(camera_group_fits(H, W, pattern, ma),
+             "%s: the frame does not fit the resident grid (mi_isp_camera_group_fits); use mi_isp_camera_frame_batch", who);
+  p.src = nullptr; p.dst = nullptr; p.fp = nullptr; p.partials = nullptr;
+  p.out_dtype = MI_U8; p.out_scale = 255.f; p.gamma_inv = 1.0f / gamma; p.la = light_adapt; p.ca = color_adapt;
+  // 1. the subsample of every camera, straight from its packed frame
+  const int Hs = (H + 7) / 8, Ws = (W + 7) / 8;
+  const size_t sub_bytes = mi_isp_camera_group_scratch_bytes(1, H, W);
+  const void* subs[mega::MAX_BATCH];
+  for (int i = 0; i < n; ++i) subs[i] = static_cast<char*>(scratch) + (size_t)i * sub_bytes;
+  for (int i0 = 0; i0 < n; i0 += strm::LOAD_BATCH) {
+    strm::SubArgs sa = {};
+    sa.t = p;
+    strm::sub_geometry(H, W, sa);
+    sa.n_batch = n - i0 < strm::LOAD_BATCH ? n - i0 : strm::LOAD_BATCH;
+    for (int i = 0; i < sa.n_batch; ++i) { sa.srcs[i] = packed[i0 + i]; sa.subs[i] = const_cast<void*>(subs[i0 + i]); }
+    if (int rc = strm::launch_sub(sa, MI_F16, pattern, s)) return rc;
+  }
+  // 2. the rolling metering over the group (its own workspace: the last of the n + 1)
+  const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
+  float* ws_meter = static_cast<float*>(ws) + (size_t)n * ws_floats;
+  if (int rc = mi_isp_metering(subs, n, Hs, Ws, 1, MI_F16, state9, alpha, ws_meter, stream)) return rc;
+  // 3. the cameras through one resident launch
+  p.part_stride = mi_partial_cap(H, W);
+  ma.t = p;
+  ma.n_px = (float)((int64_t)H * W); ma.intensity = intensity; ma.fp_w = nullptr; ma.bounds_post = 0;
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  MI_REQUIRE(dev >= 0 && dev < 16, "%s: device index %d out of range", who, dev);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  std::lock_guard<std::mutex> lock(mega_mu());
+  ew::ResidentOrder& ord = ew::resident_order();
+  if (int rc = ew::resident_mailbox_locked(dev)) return rc;
+  mega::CBatch cb = {};
+  cb.m.s = ma;
+  cb.m.spin_limit = g_cam_poll_limit ? g_cam_poll_limit : 100000;
+  cb.m.l2_first = 1;
+  cb.m.poll_sleep = 0;
+  cb.m.mailbox = ord.mailbox_dev[dev] + ew::MAILBOX_CAMERA_GROUP;
+  cb.m.sabotage_block = -1;
+  cb.m.launch_id = g_mega.launches.fetch_add(1, std::memory_order_relaxed) + 1u;
+  cb.state9 = state9;
+  cb.gamma_inv = 1.0f / gamma;
+  cb.n_frames = n;
+  for (int i = 0; i < n; ++i) {
+    cb.io[i].src = packed[i];
+    cb.io[i].p_out = images ? images[i] : nullptr;
+    cb.io[i].out = outs[i];
+    cb.io[i].ws = static_cast<float*>(ws) + (size_t)i * ws_floats;
+  }
+  const bool direct = cap == hipStreamCaptureStatusNone;
+  if (direct) { if (int rc = ew::resident_enter_locked(dev, s)) return rc; }
+  if (int rc = mega::launch_cam(cb, pattern, s)) return rc;
+  if (direct) { if (int rc = ew::resident_leave_locked(dev, s)) return rc; }
+  return 0;
 }
 
 // ---- a batch as a HIP graph: capture once, replay per step ---------------------------------------------------------

@@ -33,7 +33,7 @@ int subsample(const void* img, void* sub, int H, int W, int stride, int dtype, h
 // records the event again.  The lock is held over all three steps.  (Round 3 kept one order for the whole-frame kernel
 // and another for the metering kernel: a metering grid and a whole-frame grid on two streams could time each other out.)
 // The host-mapped mailbox page of a device (16 words) is where these kernels report a timeout without a synchronisation:
-// word 0 the whole-frame kernel, word 1 the metering kernel, word 2 the fused ISP tonemap.
+// word 0 the whole-frame kernel, word 1 the metering kernel, word 2 the fused ISP tonemap, word 3 the camera-group kernel.
 struct ResidentOrder {
   std::mutex mu;
   hipEvent_t done[16] = {};
@@ -42,7 +42,7 @@ struct ResidentOrder {
   unsigned* mailbox_host[16] = {};
   unsigned* mailbox_dev[16] = {};
 };
-enum { MAILBOX_WHOLE_FRAME = 0, MAILBOX_METERING = 1, MAILBOX_ISP_TONEMAP = 2 };
+enum { MAILBOX_WHOLE_FRAME = 0, MAILBOX_METERING = 1, MAILBOX_ISP_TONEMAP = 2, MAILBOX_CAMERA_GROUP = 3 };
 ResidentOrder& resident_order();
 // callers hold resident_order().mu; dev in [0, 16)
 int resident_mailbox_locked(int dev);                       // allocates the device's mailbox page on first use

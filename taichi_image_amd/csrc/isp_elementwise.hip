@@ -500,16 +500,8 @@ struct PassArgs {
                             // reversed list, see mi_isp_reinhard_batch)
 };
 
-// camera_isp.py:186-195: the Reinhard scalars of the ISP path from the metering 9-vector
-MI_DEV void isp_reinhard_scalars(const float* state9, float* fp, float intensity, float ca) {
-  const float bmin = state9[0], bmax = state9[1], lmin = state9[2], lmax = state9[3];
-  const float lmean = state9[4], mean = state9[5];
-  const float key = (lmax - lmean) / (lmax - lmin);
-  fp[FP_LO] = bmin; fp[FP_HI] = bmax; fp[FP_INV] = 1.0f / (bmax - bmin);
-  fp[FP_MAPKEY] = 0.3f + 0.7f * powf(key, 1.4f);
-  fp[FP_EI] = expf(-intensity);
-  for (int c = 0; c < 3; ++c) fp[FP_MEAN3 + c] = mean + ca * (state9[6 + c] - mean);
-}
+// (isp_reinhard_scalars - camera_isp.py:186-195 - lives in isp_math.h: the camera-group kernel of isp_mega_cam.h derives the
+// same scalars)
 
 // Prologue of a pass with a pulled finalize: sh_fp = the FrameParams this block works with.
 template <int FIN>
@@ -710,7 +702,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
         // camera_isp.py:200: no clamp on the normalised value here
         float t[3], q[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) t[ch] = (x[ch] - lo) * inv;
+        for (int ch = 0; ch < 3; ++ch) t[ch] = isp_norm(x[ch], lo, inv);
         reinhard_px<CA0>(t, rk, q);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = q[ch];
@@ -722,7 +714,7 @@ __global__ __launch_bounds__(PASS_THREADS, 4) void rgb_pass_kernel(const PassArg
         // p as pass 1 computes it (camera_isp.py:200-210), rounded to the image dtype as the write-back stores it (:211)
         float t[3], q[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) t[ch] = (x[ch] - lo) * inv;
+        for (int ch = 0; ch < 3; ++ch) t[ch] = isp_norm(x[ch], lo, inv);
         reinhard_px<CA0>(t, rk, q);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) o[3 * k + ch] = (float)cast_out<TI>(q[ch]) * maxout_inv;
@@ -946,7 +938,7 @@ __global__ __launch_bounds__(ISPF_THREADS, BPC) void isp_reinhard_fused_kernel(c
         for (int px = 0; px < 8; ++px) {
           float t[3], q[3];
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) t[ch] = (v[3 * px + ch] - lo) * inv;      // camera_isp.py:200: no clamp here
+          for (int ch = 0; ch < 3; ++ch) t[ch] = isp_norm(v[3 * px + ch], lo, inv);      // camera_isp.py:200: no clamp here
           reinhard_px<CA0>(t, rk, q);
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) o[3 * px + ch] = q[ch];

@@ -127,6 +127,8 @@ MI_DEV void finalize_scalars_fast(int mode, const FinArgs& a, const float* tot) 
     fp[FP_LO] = lo; fp[FP_HI] = hi; fp[FP_INV] = __builtin_amdgcn_rcpf(hi - lo);   // tonemap.py:13
   } else if (mode == FIN_BOUNDS2) {
     fp[FP_LO2] = lo; fp[FP_HI2] = hi; fp[FP_INV2] = __builtin_amdgcn_rcpf(hi - lo);
+  } else if (mode == FIN_MAXOUT) {
+    fp[FP_MAXOUT] = fmaxf(1e-6f, hi);                                               // camera_isp.py:190,213
   } else {                                                                          // FIN_STATS: tonemap.py:99-103, :115-119
     const float LN2 = 0.6931471805599453f;
     lo = fmaxf(lo, 1e-4f); hi = fmaxf(hi, 1e-4f);

@@ -79,6 +79,14 @@ MI_DEV void reinhard_px(const float (&t)[3], const ReinhardK& k, float (&out)[3]
   }
 }
 
+// camera_isp.py:200: the ISP's normalisation, no clamp.  The value is ROUNDED where it is made (f32_rounded: an empty asm the
+// contraction pass cannot look through): under `contract(fast)` the product would otherwise be free to fuse with whatever
+// adds to it downstream - `ad + t` of reinhard_map, `t - g` of the colour adaptation - in one kernel and not in another,
+// and the kernels that map the same pixel (pass 1, the recomputing pass 2, the one-launch tonemap, the camera-group
+// kernel of isp_mega_cam.h) must agree to the bit.  (Round 4: pass 1 had fused, the camera-group kernel had not - p
+// differed in the last bit for ~1 pixel in 20 000 whenever the bounds were not exactly (0, 1).)
+MI_DEV float isp_norm(float x, float lo, float inv) { return f32_rounded((x - lo) * inv); }
+
 // tonemap.py:12-17: clamp(((x-lo)*inv)^(1/gamma), 0, 1) * scale.  gamma_inv == 1 skips the pow
 // (powf(x, 1) == x exactly).  NaN -> 0 through fmaxf.
 MI_DEV float linear_px(float x, float lo, float inv, float gamma_inv, float scale) {
@@ -108,3 +116,15 @@ MI_DEV void linear_n(float (&v)[N], float lo, float inv, float gamma_inv, float 
 }
 
 #pragma clang fp contract(off)
+
+// camera_isp.py:186-195: the Reinhard scalars of the ISP path from the metering 9-vector (no contraction: the two
+// kernels that derive them - rgb_pass_kernel<PM_ISP_RH_P1>, mega::camera_kernel - must get the same bits)
+MI_DEV void isp_reinhard_scalars(const float* state9, float* fp, float intensity, float ca) {
+  const float bmin = state9[0], bmax = state9[1], lmin = state9[2], lmax = state9[3];
+  const float lmean = state9[4], mean = state9[5];
+  const float key = (lmax - lmean) / (lmax - lmin);
+  fp[FP_LO] = bmin; fp[FP_HI] = bmax; fp[FP_INV] = 1.0f / (bmax - bmin);
+  fp[FP_MAPKEY] = 0.3f + 0.7f * powf(key, 1.4f);
+  fp[FP_EI] = expf(-intensity);
+  for (int c = 0; c < 3; ++c) fp[FP_MEAN3 + c] = mean + ca * (state9[6 + c] - mean);
+}

@@ -848,6 +848,93 @@ __global__ __launch_bounds__(THREADS, 2) void stream_kernel(const SArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stride-8 subsample ISP.update_metering reads (camera_isp.py:168-170: image[::8, ::8]) straight from the PACKED
+// frame, without the image: only the rows r % 8 == 0 are demosaiced - five packed rows in, one sample per unit out.
+// For callers that want a camera group's metering BEFORE its images exist (mi_isp_camera_group_reinhard: the Reinhard
+// scalars come from the metering, so a kernel that tone-maps while it demosaics needs them first).  The same decode
+// table, window, accumulate_row, border fixes, colour matrix, clamp and rounding as stream_kernel<S_STORE>: the samples
+// are the bits its epilogue writes (tests/: compared with the subsample of the loaded image).  A wave = one sample row
+// of one band; 1 / 8 of the demosaic and 5 / 8 of the decode of a full pass.
+struct SubArgs {
+  Params t;
+  int bands_x, n_waves, n_blocks;
+  int sub_w;              // ceil(W / 8)
+  int n_batch;            // >= 1: grid.y = frame; frame y reads srcs[y], writes subs[y]
+  const void* srcs[LOAD_BATCH];
+  void* subs[LOAD_BATCH];
+};
+
+template <class E, int PR, int PC>
+__global__ __launch_bounds__(THREADS) void sub_kernel(const SubArgs a) {
+  constexpr bool EXACT = sizeof(E) == 2;
+  const Params& p = a.t;
+  __shared__ float lut[4096];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blockIdx.x * WAVES + wave;
+  const bool wave_ok = g < a.n_waves;
+  const int by = g / a.bands_x, bx = g - by * a.bands_x;
+  const int c0 = bx * BAND + lane * 8;
+  const int row = by * 8;                              // the sample row (even: strip row 0 of its row pair)
+  const bool col_ok = wave_ok && c0 < p.W;
+  const uint32_t pitch = (uint32_t)p.W * 3 / 2;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.srcs[blockIdx.y]), 0,
+                                                                        (int)((uint32_t)p.H * pitch), 0x00020000);
+  const uint32_t col_off = col_ok ? (uint32_t)c0 * 3 / 2 : INVALID_OFF;
+  const bool ext_ok = col_ok && ((lane == 0 && c0 > 0) || (lane == 63 && c0 + 8 < p.W));
+  const uint32_t ext_off = ext_ok ? (uint32_t)c0 * 3 / 2 + (lane == 0 ? -4 : 12) : INVALID_OFF;
+  uint32_t raw[5][4];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {                        // rows row - 2 .. row + 2; outside the image: zeros (as stream_kernel)
+    const int r = row - 2 + q;
+    const uint32_t row_off = (wave_ok && r >= 0 && r < p.H) ? (uint32_t)r * pitch : INVALID_OFF;
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const u3 d = __builtin_amdgcn_raw_buffer_load_b96(rsrc, col_off + row_off, 0, 0);
+    raw[q][0] = d.x; raw[q][1] = d.y; raw[q][2] = d.z;
+    raw[q][3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ext_off + row_off, 0, 0);
+  }
+  for (int e = threadIdx.x; e < 4096; e += THREADS) lut[e] = tile::decode_scaled<E>((uint32_t)e, p.k_decode);
+  __syncthreads();
+  float wq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wq[i] = vgpr(wq_value(i));
+  WinRow w6[6];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) decode_row(raw[q], lut, lane, w6[q]);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) w6[5].v[j] = 0.f;         // (strip row 0 does not look at the window's sixth row)
+  const bool is_left = col_ok && c0 == 0, is_right = col_ok && c0 + 8 == p.W;
+  const bool any_left = __builtin_amdgcn_ballot_w64(is_left) != 0, any_right = __builtin_amdgcn_ballot_w64(is_right) != 0;
+  float v[24];
+  accumulate_row<PR, PC, 0, EXACT>(w6, wq, v);
+  if (row < 2 || row >= p.H - 2) border_fix_rows<PR, PC, 0>(v, tile::inside_mask(row, p.H), is_left, is_right);
+  else if (any_left || any_right) border_fix_cols<PR, PC, 0>(v, is_left, is_right, any_left, any_right);
+  float x = v[0], y = v[1], z = v[2];                  // the lane's first pixel = column c0 = a multiple of 8
+  if (p.has_ccm) {                                     // bayer.py:152-153, sequential fp32 dot
+    float o[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) o[ch] = (p.ccm[3 * ch] * x + p.ccm[3 * ch + 1] * y) + p.ccm[3 * ch + 2] * z;
+    x = o[0]; y = o[1]; z = o[2];
+  }
+  if (!col_ok || row >= p.H) return;
+  E* sp = static_cast<E*>(a.subs[blockIdx.y]) + ((size_t)by * a.sub_w + (size_t)(c0 >> 3)) * 3;
+  if constexpr (sizeof(E) == 2) {
+    const uint32_t p0 = tile::cvt_pk_f16_clamp01(x, y), p1 = tile::cvt_pk_f16_clamp01(z, 0.f);
+    uint16_t* s16 = reinterpret_cast<uint16_t*>(sp);
+    s16[0] = (uint16_t)(p0 & 0xFFFFu); s16[1] = (uint16_t)(p0 >> 16); s16[2] = (uint16_t)(p1 & 0xFFFFu);
+  } else {
+    sp[0] = (E)clamp01(x); sp[1] = (E)clamp01(y); sp[2] = (E)clamp01(z);
+  }
+}
+
+static inline void sub_geometry(int H, int W, SubArgs& a) {
+  a.bands_x = (W + BAND - 1) / BAND;
+  a.sub_w = (W + 7) / 8;
+  a.n_waves = a.bands_x * ((H + 7) / 8);
+  a.n_blocks = (a.n_waves + WAVES - 1) / WAVES;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 // geometry: bands of 512 columns; rows per wave chosen so that the grid holds about 2 waves per SIMD
 static inline void geometry(int H, int W, SArgs& a) {
@@ -874,6 +961,18 @@ static inline bool supported(const Params& p, int work_dtype) {
          (work_dtype == MI_F16 || work_dtype == MI_F32) && (int64_t)p.H * p.W * 3 / 2 < (int64_t)0x40000000;
 }
 
+int launch_sub_rggb(const SubArgs& a, int work_dtype, hipStream_t stream);
+int launch_sub_grbg(const SubArgs& a, int work_dtype, hipStream_t stream);
+int launch_sub_gbrg(const SubArgs& a, int work_dtype, hipStream_t stream);
+int launch_sub_bggr(const SubArgs& a, int work_dtype, hipStream_t stream);
+static inline int launch_sub(const SubArgs& a, int work_dtype, int pattern, hipStream_t stream) {
+  switch (pattern) {
+    case MI_RGGB: return launch_sub_rggb(a, work_dtype, stream);
+    case MI_GRBG: return launch_sub_grbg(a, work_dtype, stream);
+    case MI_GBRG: return launch_sub_gbrg(a, work_dtype, stream);
+    default: return launch_sub_bggr(a, work_dtype, stream);
+  }
+}
 int launch_rggb(const SArgs& a, int work_dtype, int epi, hipStream_t stream);
 int launch_grbg(const SArgs& a, int work_dtype, int epi, hipStream_t stream);
 int launch_gbrg(const SArgs& a, int work_dtype, int epi, hipStream_t stream);

@@ -465,6 +465,41 @@ def test_camera_frame_batch_through_the_c_abi(ti, dev, rng, tonemap, resize_widt
             assert torch.equal(images[k], want_imgs[k]), f"group {group} camera {k}: image left behind"
 
 
+def test_camera_group_reinhard_through_the_c_abi_full_size(ti, dev, scenes):
+    """mi_isp_camera_group_reinhard straight through ctypes at 4096 x 3072: three cameras, two groups (rolling metering),
+    once without images (the reference bench's form) and once with: u8 outputs, p and state equal to the Python ISP's
+    load_packed12 x n + tonemap_reinhard - which the other tests pin against the oracle - bit for bit."""
+    import ctypes
+    from taichi_image_amd import _native
+    L = _native.lib()
+    H, W, n = 3072, 4096, 3
+    assert L.mi_isp_camera_group_fits(H, W, 0, ti.types.f16.code, 8) == 1
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.25, device=dev)
+    state = torch.zeros(9, dtype=torch.float32, device=dev)
+    images = [torch.empty((H, W, 3), dtype=torch.float16, device=dev) for _ in range(n)]
+    outs = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(n)]
+    ws = torch.zeros(int(L.mi_isp_workspace_bytes(H, W)) * (n + 1), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(int(L.mi_isp_camera_group_scratch_bytes(n, H, W)), dtype=torch.uint8, device=dev)
+    for group in range(2):
+        packs = [torch.from_numpy(packed_from(scenes[k], GAINS[(k + group) % len(GAINS)], OFFSETS[(k + group) % len(OFFSETS)])).to(dev)
+                 for k in range(n)]
+        want_imgs = [isp.load_packed12(p) for p in packs]
+        want = isp.tonemap_reinhard(want_imgs, gamma=0.6, intensity=1.2, light_adapt=0.8, color_adapt=0.0)
+        alpha = 0.0 if group == 0 else 1.0 - 0.25
+        rc = L.mi_isp_camera_group_reinhard(_native.ptr_array(packs), _native.ptr_array(images) if group == 1 else None,
+                                            _native.ptr_array(outs), n, H, W, 0, None, state.data_ptr(), ctypes.c_float(alpha),
+                                            ctypes.c_float(0.6), ctypes.c_float(1.2), ctypes.c_float(0.8), ctypes.c_float(0.0),
+                                            scratch.data_ptr(), ws.data_ptr(), _native.stream_ptr(dev))
+        assert rc == 0, L.mi_isp_last_error()
+        torch.cuda.synchronize()
+        assert L.mi_isp_camera_group_faults(0) == 0
+        assert torch.equal(state, isp.metrics), f"group {group}: metering state"
+        for k in range(n):
+            assert torch.equal(outs[k], want[k]), f"group {group} camera {k}: u8 output"
+            if group == 1:
+                assert torch.equal(images[k].view(torch.int16), want_imgs[k].view(torch.int16)), f"group {group} camera {k}: p"
+
+
 def test_isp_reuse_of_tonemapped_images_full_size(ti, dev, scenes):
     """Two 4096 x 3072 cameras through tonemap_reinhard twice (camera_isp.py:211 then :376-403 again): the second call
     meters the images the first one overwrote, not the subsample their load kernel left (the round-3 hole)."""

@@ -907,6 +907,111 @@ def test_isp_reinhard_one_launch_timeout_is_reported(ti, dev, monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(again, good)) and L.mi_isp_reinhard_faults(0) == 0
 
 
+@pytest.mark.parametrize("shape,n,pattern,kw,cc", [
+    ((48, 64), 3, "RGGB", dict(), False), ((36, 520), 2, "GRBG", dict(gamma=0.6), True),
+    ((100, 1032), 4, "BGGR", dict(gamma=0.6, color_adapt=0.3, intensity=1.2, light_adapt=0.7), True),
+    ((768, 1024), 6, "GBRG", dict(gamma=2.2), False), ((26, 4096), 2, "RGGB", dict(gamma=0.6), False)])
+def test_isp_process_packed12_equals_the_two_calls(ti, dev, shape, n, pattern, kw, cc):
+    """Extension: ISP.process_packed12 - the reference bench's Processor step (bench/camera_isp.py:23-27) in one call, on the
+    camera-group kernel (csrc/isp_mega_cam.h: subsample from the packed frames, metering, ONE persistent launch from packed
+    bytes to u8) - gives the u8 outputs, the images the reference leaves behind (p, camera_isp.py:211) and the metering
+    state of `tonemap_reinhard([load_packed12(f) ...])` bit for bit, over three groups of a rolling metering; rows that do
+    not fill a wave's 12, bands narrower than 512 columns, image borders, all four patterns, the colour matrix."""
+    from taichi_image_amd import _native
+    L = _native.lib()
+    H, W = shape
+    pat = getattr(ti.BayerPattern, pattern)
+    assert L.mi_isp_camera_group_fits(H, W, pat.value, ti.types.f16.code, 8) == 1
+    a = ti.Camera16(pat, moving_alpha=0.3, correct_colors=cc, device=dev)
+    b = ti.Camera16(pat, moving_alpha=0.3, correct_colors=cc, device=dev)
+    for group in range(3):
+        frames = [torch.from_numpy(natural_packed12(np.random.default_rng(1000 + 10 * group + k), H, W, dark=0.03 * k)).to(dev)
+                  for k in range(n)]
+        keep = group != 1                                 # (the bench's form - nothing kept - in the middle group)
+        got = a.process_packed12(frames, keep_images=keep, **kw)
+        outs, images = got if keep else (got, None)
+        want_images = [b.load_packed12(f) for f in frames]
+        want = b.tonemap_reinhard(want_images, **kw)
+        torch.cuda.synchronize()
+        assert L.mi_isp_camera_group_faults(0) == 0
+        assert torch.equal(a.metrics.view(torch.int32), b.metrics.view(torch.int32)), f"group {group}: metering state"
+        for k in range(n):
+            assert torch.equal(outs[k], want[k]), f"group {group} camera {k}: u8 output"
+            if keep:
+                assert torch.equal(images[k].view(torch.int16), want_images[k].view(torch.int16)), f"group {group} camera {k}: p"
+
+
+def test_isp_process_packed12_against_the_oracle(ti, dev):
+    """The same call against the oracle's load -> update_metering -> reinhard_isp (camera_isp.py:333-340,376-385,177-218)."""
+    from oracle import c_oracle
+    H, W, n = 96, 1024, 3
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+    st = c_oracle.IspState(0.3)
+    for group in range(2):
+        packs = [natural_packed12(np.random.default_rng(1100 + 10 * group + k), H, W, dark=0.02 * k) for k in range(n)]
+        outs, images = isp.process_packed12([torch.from_numpy(p).to(dev) for p in packs], gamma=0.6, keep_images=True)
+        refs = [O.isp_load_packed12(p, "f16") for p in packs]
+        m = st.update_metering(refs)
+        assert_close(isp.metrics.cpu().numpy(), m, f"group {group}: metrics", rel=2e-5)
+        for k in range(n):
+            ref_u8, ref_after = c_oracle.reinhard_isp(refs[k], m, gamma=0.6)
+            assert_close(outs[k].cpu().numpy(), ref_u8, f"group {group} camera {k}: u8")
+            assert_close(images[k].cpu().numpy(), ref_after, f"group {group} camera {k}: p")
+
+
+def test_isp_process_packed12_falls_back_to_the_two_calls(ti, dev):
+    """What the camera-group kernel does not take - Camera32, a resize, an orientation transform, another metering stride -
+    goes through load_packed12_batch + tonemap_reinhard: same results as the two calls, whatever the path."""
+    H, W, n = 64, 512, 2
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(1200 + k), H, W, dark=0.03 * k)).to(dev) for k in range(n)]
+    for cam, extra in (("Camera32", {}), ("Camera16", dict(resize_width=256)), ("Camera16", dict(transform=ti.ImageTransform.rotate_90)),
+                       ("Camera16", dict(metering_stride=4))):
+        a = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, **extra)
+        b = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, **extra)
+        outs, images = a.process_packed12(frames, gamma=0.6, keep_images=True)
+        want_images = [b.load_packed12(f) for f in frames]
+        want = b.tonemap_reinhard(want_images, gamma=0.6)
+        assert torch.equal(a.metrics, b.metrics), (cam, extra)
+        for k in range(n):
+            bits = torch.int16 if cam == "Camera16" else torch.int32             # (bit views: p may hold NaN)
+            assert torch.equal(outs[k], want[k]) and torch.equal(images[k].view(bits), want_images[k].view(bits)), (cam, extra, k)
+
+
+def test_isp_process_packed12_timeout_is_reported(ti, dev):
+    """The camera-group kernel's wait for max_out with a budget of one poll: the first block to look gives up - the camera's
+    fault word, the device's mailbox word, TonemapTimeout at the next call - nothing hangs, and the call after is clean."""
+    from taichi_image_amd import _native
+    from taichi_image_amd.camera_isp import TonemapTimeout
+    L = _native.lib()
+    H, W = 768, 1024
+    frames = [torch.from_numpy(natural_packed12(np.random.default_rng(1300 + k), H, W)).to(dev) for k in range(3)]
+    isp = ti.Camera16(ti.BayerPattern.RGGB, device=dev)
+    good = isp.process_packed12(frames, gamma=0.6)
+    torch.cuda.synchronize()
+    assert L.mi_isp_camera_group_faults(1) == 0
+    L.mi_isp_camera_group_set_poll_limit(1)
+    try:
+        isp.process_packed12(frames, gamma=0.6)
+        torch.cuda.synchronize()
+    finally:
+        L.mi_isp_camera_group_set_poll_limit(0)
+    assert L.mi_isp_camera_group_faults(0) != 0
+    ws = _native.workspace(H, W, dev, slots=len(frames) + 1)
+    off, per = int(L.mi_isp_workspace_error_offset(H, W)), int(L.mi_isp_workspace_bytes(H, W))
+    words = [int(ws[i * per + off:i * per + off + 4].view(torch.int32).item()) for i in range(len(frames))]
+    assert any(words), "no camera's fault word was set"
+    import ctypes
+    n_failed = ctypes.c_int(0)
+    assert L.mi_isp_workspace_check(ws.data_ptr(), len(frames), H, W, None, ctypes.byref(n_failed), _native.stream_ptr(dev)) == 0
+    assert n_failed.value == sum(1 for w in words if w)
+    with pytest.raises(TonemapTimeout):
+        isp.process_packed12(frames, gamma=0.6)
+    isp2 = ti.Camera16(ti.BayerPattern.RGGB, device=dev)
+    again = isp2.process_packed12(frames, gamma=0.6)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(again, good)) and L.mi_isp_camera_group_faults(0) == 0
+
+
 def test_resident_grids_of_both_kinds_share_one_order(ti, dev):
     """A one-launch metering grid and a whole-frame grid on two streams: each needs all its blocks resident, so the library
     puts them in ONE order (round 3 kept two, and the two kinds could hold half of the chip each until their budgets ran
