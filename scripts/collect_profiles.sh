@@ -18,4 +18,8 @@ cp $P/kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
   grep -v amdgpu $P/whole_frame_skew.txt; } > profiles/${TAG}_whole_frame_skew.txt
 { echo "# scripts/pmc_mix.sh profile_${TAG}_mix 'prof_batch.py 64 3': dynamic instruction mix of mega::frame_kernel per LAUNCH of 64 frames (divide by 64 for a frame), the round's final kernel, MI355X, commit $C"
   sed -n '/mega::frame_kernel/,$p' $P/whole_frame_mix_batch64.txt; } > profiles/${TAG}_whole_frame_mix.txt
+if [ -f $P/camera_group_kernel_stats.txt ]; then
+{ echo "# scripts/profile_round4.sh: rocprofv3 --kernel-trace --stats of scripts/prof_cam.py (ISP.process_packed12, 6 cameras at 4096 x 3072, gamma 0.6, images not kept: 30 steps), then scripts/time_cam.py; MI355X, commit $C"
+  grep -v amdgpu $P/camera_group_kernel_stats.txt; } > profiles/${TAG}_camera_group_kernel_stats.txt
+fi
 git status --short profiles | head -20

@@ -17,4 +17,10 @@ if [ -f $R/taichi_image_amd/lib/libmi355_isp_stamps.so ]; then
   MI_ISP_LIB=$R/taichi_image_amd/lib/libmi355_isp_stamps.so timeout -k 10 200 python3 $R/scripts/wf_skew.py > $OUT/whole_frame_skew.txt 2>&1 || true
 fi
 python3 $R/scripts/time_isp.py > $OUT/time_isp.txt 2>&1
+# the camera-group path (ISP.process_packed12): its three kernels per 6-camera step, and the step's time beside the two-call sequence
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cam_trace -- python3 $R/scripts/prof_cam.py 0 > $OUT/cam_trace.log 2>&1 || exit 1
+cd $R
+find $OUT/cam_trace -name "*kernel_stats.csv" -exec cat {} + < /dev/null | cut -c1-160 | head -6 > $OUT/camera_group_kernel_stats.txt
+python3 $R/scripts/time_cam.py >> $OUT/camera_group_kernel_stats.txt 2>&1
 cat $OUT/isp_kernel_stats.txt
