@@ -178,8 +178,12 @@ def timed(fn, steps, warmup, device, barrier=None, local=None):
     return time.perf_counter() - t0
 
 
-def isp_step_fn(frames_dev, device, process_group=None):
+def isp_step_fn(frames_dev, device, process_group=None, full_res=False):
     import taichi_image_amd as ti
+    if full_res:
+        # the reference bench's step (bench/camera_isp.py:23-27) at full resolution, as one call (csrc/isp_mega_cam.h)
+        isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, device=device, process_group=process_group)
+        return lambda: isp.process_packed12(frames_dev, gamma=0.6)
     isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.1, resize_width=1920, device=device,
                       process_group=process_group)
     return lambda: isp.tonemap_reinhard([isp.load_packed12(f) for f in frames_dev], gamma=0.6)
@@ -189,11 +193,15 @@ def isp_workload(args, rank, world, device):
     """Configs 3 / 5: the stateful Camera16 chain on `--frames` cameras per rank per step."""
     import torch.distributed as dist
     from taichi_image_amd import synthetic
-    shared = args.workload == "isp-shared-stats"
+    shared = args.workload.endswith("shared-stats")
+    full_res = args.workload.startswith("camera-group")
+    if full_res and world > 1 and world > torch.cuda.device_count():
+        # (ranks that share a GPU - the gloo rehearsal - would put two resident grids on one chip)
+        sys.exit("bench.py: the camera-group workloads need one GPU per rank")
     group = dist.group.WORLD if (shared and world > 1) else None
     host, slot = host_frames(rank * args.frames, args.frames, min(4, args.frames))
     frames = [torch.from_numpy(host[slot[i]]).to(device) for i in range(args.frames)]
-    step = isp_step_fn(frames, device, group)
+    step = isp_step_fn(frames, device, group, full_res)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -222,7 +230,7 @@ def isp_workload(args, rank, world, device):
         if ev:
             collective_us = round(sum(e0.elapsed_time(e1) for e0, e1 in ev) * 1e3 / 8, 2)
     if rank == 0:
-        out_bytes = 1440 * 1920 * 3
+        out_bytes = H * W * 3 if full_res else 1440 * 1920 * 3
         print(json.dumps({
             **run_identity(world, os.environ.get("MI_ISP_BENCH_BACKEND", "nccl")),
             "us_per_frame_by_rank": per_rank,
@@ -233,8 +241,12 @@ def isp_workload(args, rank, world, device):
             "value": round(world * args.frames * args.steps * MP / elapsed, 1), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("config 5" if shared else "config 3") + ": Camera16(RGGB, resize_width=1920, "
-                       "moving_alpha=0.1) load_packed12 x frames + tonemap_reinhard(gamma=0.6) -> u8 1920x1440"
+            "config": {"workload": (("config 5 at full resolution" if shared else "the reference's bench step (bench/camera_isp.py:19-28)")
+                                    + ": Camera16(RGGB, moving_alpha=0.1).process_packed12(frames, gamma=0.6) -> u8 4096x3072, "
+                                    "one call per step (subsample from the packed frames -> metering -> one persistent launch)"
+                                    if full_res else
+                                    ("config 5" if shared else "config 3") + ": Camera16(RGGB, resize_width=1920, "
+                                    "moving_alpha=0.1) load_packed12 x frames + tonemap_reinhard(gamma=0.6) -> u8 1920x1440")
                        + (", metering all-reduced over ranks (RCCL)" if shared else ""),
                        "frames_per_rank_per_step": args.frames},
             "us_per_frame": round(elapsed / (args.frames * args.steps) * 1e6, 2),
@@ -433,10 +445,11 @@ def main():
                     help="skip the single-frame launches behind the timed region (profiling: every launch the profiler sees "
                          "is then a headline launch)")
     ap.add_argument("--no-other-workloads", action="store_true")
-    ap.add_argument("--workload", default="config2", choices=["config2", "isp", "isp-shared-stats"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "isp", "isp-shared-stats", "camera-group", "camera-group-shared-stats"],
                     help="config2 (default, the BASELINE metric) | isp: Camera16(resize_width=1920) load_packed12 + "
                          "tonemap_reinhard(gamma=0.6), config 3 | isp-shared-stats: the same with the rolling metering "
-                         "statistics all-reduced over the ranks (config 5)")
+                         "statistics all-reduced over the ranks (config 5) | camera-group[-shared-stats]: full-resolution "
+                         "Camera16.process_packed12 (the reference bench's step as one call), optionally with the shared metering")
     args = ap.parse_args()
     isp = args.workload != "config2"
     if args.steps is None:

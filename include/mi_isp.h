@@ -256,6 +256,17 @@ int mi_isp_camera_group_reinhard(const uint8_t* const* packed_host, void* const*
                                  int n, int H, int W, int pattern, const float* ccm9_host, float* state9_dev, float alpha,
                                  float gamma, float intensity, float light_adapt, float color_adapt, void* scratch_dev,
                                  void* ws_dev, void* stream);
+/* The same in its steps, for callers that put something between them (taichi_image_amd: the sharded metering of a
+ * multi-GPU group, two all-gathers between the subsample and the tone map):
+ *   mi_isp_camera_group_subsample: image[::8, ::8] of every camera's (never materialised) image - (ceil(H / 8), ceil(W / 8), 3)
+ *     f16 each, camera i at scratch_dev + i * mi_isp_camera_group_scratch_bytes(1, H, W) - for mi_isp_metering (stride 1);
+ *   mi_isp_camera_group_tonemap: the persistent launch, with the Reinhard scalars of state9_dev (read on the device);
+ *     ws_dev: n x mi_isp_workspace_bytes(H, W). */
+int mi_isp_camera_group_subsample(const uint8_t* const* packed_host, int n, int H, int W, int pattern, const float* ccm9_host,
+                                  void* scratch_dev, void* stream);
+int mi_isp_camera_group_tonemap(const uint8_t* const* packed_host, void* const* images_host, uint8_t* const* outs_host, int n,
+                                int H, int W, int pattern, const float* ccm9_host, const float* state9_dev, float gamma,
+                                float intensity, float light_adapt, float color_adapt, void* ws_dev, void* stream);
 int mi_isp_camera_group_fits(int H, int W, int pattern, int work_dtype, int metering_stride);
 size_t mi_isp_camera_group_scratch_bytes(int n, int H, int W);
 int mi_isp_camera_group_faults(int clear);

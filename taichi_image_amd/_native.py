@@ -72,6 +72,9 @@ SIGNATURES = {
                                           c_float, c_float, c_float, c_int, _P, _P]),
     "mi_isp_camera_group_reinhard": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, POINTER(c_float),
                                              _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P]),
+    "mi_isp_camera_group_subsample": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),
+    "mi_isp_camera_group_tonemap": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, POINTER(c_float),
+                                            _P, c_float, c_float, c_float, c_float, _P, _P]),
     "mi_isp_camera_group_fits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mi_isp_camera_group_scratch_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "mi_isp_camera_group_faults": (c_int, [c_int]),

@@ -362,7 +362,7 @@ def camera_isp(name: str, dtype=types.f32):
             rgb = bayer.bayer_to_rgb(cfa, pattern=self._demosaic_pattern, correct_colors=self.color_correct_matrix)
             return self.resize_image(rgb)
 
-        def _metering_images(self, images, t, prev):
+        def _metering_images(self, images, t, prev, stride=None):
             """camera_isp.py:168-175: statistics of the stride-subsampled images, blended into a
             copy of `prev`; the subsample is gathered in-kernel (no torch.stack copy)."""
             assert len(images) > 0, "need at least one image"
@@ -371,7 +371,7 @@ def camera_isp(name: str, dtype=types.f32):
                 assert im.shape == images[0].shape, "all images of one call must share a shape"
             H, W = images[0].shape[:2]
             ws = _native.workspace(H, W, self.device)
-            stride = self.metering_stride
+            stride = self.metering_stride if stride is None else stride       # (stride=1: the caller hands over subsamples)
             # images that came out of load_packed12 / 16 carry their subsample: the same samples in the same order from a
             # dense buffer (stride 1) - identical results, no strided gather over the full-size images
             subs = [_valid_subsample(im, stride) for im in images]
@@ -504,7 +504,7 @@ def camera_isp(name: str, dtype=types.f32):
             assert len(frames) > 0, "need at least one frame"
             L = _native.lib()
             f0 = frames[0]
-            fused = (dtype is types.f16 and self.process_group is None and self.resize_width == 0 and self.scale is None
+            fused = (dtype is types.f16 and self.resize_width == 0 and self.scale is None
                      and self.transform == interpolate.ImageTransform.none and self.metering_stride == 8
                      and 1 <= len(frames) <= 64
                      and all(isinstance(f, torch.Tensor) and f.ndim == 2 and f.dtype == torch.uint8 and f.shape == f0.shape
@@ -535,12 +535,26 @@ def camera_isp(name: str, dtype=types.f32):
                 metrics, t = self.metrics.clone(), 1.0 - self.moving_alpha
             scratch = torch.empty(int(L.mi_isp_camera_group_scratch_bytes(n, h, w)), dtype=torch.uint8, device=self.device)
             ws = _native.workspace(h, w, self.device, slots=n + 1)
-            _native.check(L.mi_isp_camera_group_reinhard(
-                _native.ptr_array(srcs), _native.ptr_array(images) if keep_images else None, _native.ptr_array(outputs), n,
-                h, w, self._demosaic_pattern.value, _native.ccm_arg(self.color_correct_matrix), metrics.data_ptr(),
-                float(t), float(gamma), float(intensity), float(light_adapt), float(color_adapt), scratch.data_ptr(),
-                ws.data_ptr(), _native.stream_ptr(self.device)))
-            self.metrics = metrics
+            stream = _native.stream_ptr(self.device)
+            p_srcs, p_imgs, p_outs = _native.ptr_array(srcs), _native.ptr_array(images) if keep_images else None, _native.ptr_array(outputs)
+            ccm = _native.ccm_arg(self.color_correct_matrix)
+            if self.process_group is None:
+                _native.check(L.mi_isp_camera_group_reinhard(
+                    p_srcs, p_imgs, p_outs, n, h, w, self._demosaic_pattern.value, ccm, metrics.data_ptr(), float(t),
+                    float(gamma), float(intensity), float(light_adapt), float(color_adapt), scratch.data_ptr(), ws.data_ptr(),
+                    stream))
+                self.metrics = metrics
+                return (outputs, images) if keep_images else outputs
+            # a sharded group (one process per GPU): the same three steps with the metering's two all-gathers in between
+            _native.check(L.mi_isp_camera_group_subsample(p_srcs, n, h, w, self._demosaic_pattern.value, ccm,
+                                                          scratch.data_ptr(), stream))
+            per = int(L.mi_isp_camera_group_scratch_bytes(1, h, w))
+            hs, ws_ = (h + 7) // 8, (w + 7) // 8
+            subs = [scratch[i * per:i * per + hs * ws_ * 6].view(torch_dtype).view(hs, ws_, 3) for i in range(n)]
+            self.metrics = self._metering_images(subs, t, metrics, stride=1)
+            _native.check(L.mi_isp_camera_group_tonemap(
+                p_srcs, p_imgs, p_outs, n, h, w, self._demosaic_pattern.value, ccm, self.metrics.data_ptr(), float(gamma),
+                float(intensity), float(light_adapt), float(color_adapt), ws.data_ptr(), stream))
             return (outputs, images) if keep_images else outputs
 
         def tonemap_linear(self, images: List[torch.Tensor], gamma: float = 1.0):

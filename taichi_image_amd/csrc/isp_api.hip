@@ -810,19 +810,14 @@ extern "C" int mi_isp_camera_group_faults(int clear) {
   return (int)v;
 }
 
-extern "C" int mi_isp_camera_group_reinhard(const uint8_t* const* packed, void* const* images, uint8_t* const* outs, int n,
-                                            int H, int W, int pattern, const float* ccm9, float* state9, float alpha,
-                                            float gamma, float intensity, float light_adapt, float color_adapt,
-                                            void* scratch, void* ws, void* stream) {
-  const char* who = "camera_group_reinhard";
-  MI_REQUIRE(packed && outs && state9 && scratch && ws, "%s: null pointer", who);
+// the frames' common parameters, checked per camera
+static int camera_group_params(tile::Params& p, const uint8_t* const* packed, void* const* images, uint8_t* const* outs, int n,
+                               int H, int W, int pattern, const float* ccm9, const char* who) {
+  MI_REQUIRE(packed, "%s: null pointer", who);
   MI_REQUIRE(n >= 1 && n <= mega::MAX_BATCH, "%s: 1 .. %d cameras per call", who, mega::MAX_BATCH);
-  MI_REQUIRE(gamma > 0.f, "%s: gamma must be positive", who);
-  hipStream_t s = (hipStream_t)stream;
-  tile::Params p = {};
   for (int i = 0; i < n; ++i) {
-    MI_REQUIRE(packed[i] && outs[i] && (!images || images[i]), "%s: camera %d has a null buffer", who, i);
-    MI_REQUIRE(((uintptr_t)outs[i] & 7) == 0 && (!images || ((uintptr_t)images[i] & 15) == 0),
+    MI_REQUIRE(packed[i] && (!outs || outs[i]) && (!images || images[i]), "%s: camera %d has a null buffer", who, i);
+    MI_REQUIRE((!outs || ((uintptr_t)outs[i] & 7) == 0) && (!images || ((uintptr_t)images[i] & 15) == 0),
                "%s: camera %d: outputs must be 8-byte, images 16-byte aligned", who, i);
     tile::Params pi = {};
     if (int rc = fill_common(pi, H, W, pattern, ccm9, who)) return rc;
@@ -831,32 +826,47 @@ extern "C" int mi_isp_camera_group_reinhard(const uint8_t* const* packed, void* 
                "(standard 12-bit layout, W %% 8 == 0, even H, 4-byte aligned rows)", who, i);
     if (i == 0) p = pi;
   }
-  strm::SArgs ma = {};
-  MI_REQUIRE(camera_group_fits(H, W, pattern, ma),
-             "%s: the frame does not fit the resident grid (mi_isp_camera_group_fits); use mi_isp_camera_frame_batch", who);
   p.src = nullptr; p.dst = nullptr; p.fp = nullptr; p.partials = nullptr;
-  p.out_dtype = MI_U8; p.out_scale = 255.f; p.gamma_inv = 1.0f / gamma; p.la = light_adapt; p.ca = color_adapt;
-  // 1. the subsample of every camera, straight from its packed frame
-  const int Hs = (H + 7) / 8, Ws = (W + 7) / 8;
+  return 0;
+}
+
+// step 1: image[::8, ::8] of every camera's (never materialised) image, (ceil(H / 8), ceil(W / 8), 3) f16 each, in scratch
+extern "C" int mi_isp_camera_group_subsample(const uint8_t* const* packed, int n, int H, int W, int pattern, const float* ccm9,
+                                             void* scratch, void* stream) {
+  const char* who = "camera_group_subsample";
+  MI_REQUIRE(scratch, "%s: null pointer", who);
+  tile::Params p = {};
+  if (int rc = camera_group_params(p, packed, nullptr, nullptr, n, H, W, pattern, ccm9, who)) return rc;
   const size_t sub_bytes = mi_isp_camera_group_scratch_bytes(1, H, W);
-  const void* subs[mega::MAX_BATCH];
-  for (int i = 0; i < n; ++i) subs[i] = static_cast<char*>(scratch) + (size_t)i * sub_bytes;
   for (int i0 = 0; i0 < n; i0 += strm::LOAD_BATCH) {
     strm::SubArgs sa = {};
     sa.t = p;
     strm::sub_geometry(H, W, sa);
     sa.n_batch = n - i0 < strm::LOAD_BATCH ? n - i0 : strm::LOAD_BATCH;
-    for (int i = 0; i < sa.n_batch; ++i) { sa.srcs[i] = packed[i0 + i]; sa.subs[i] = const_cast<void*>(subs[i0 + i]); }
-    if (int rc = strm::launch_sub(sa, MI_F16, pattern, s)) return rc;
+    for (int i = 0; i < sa.n_batch; ++i) { sa.srcs[i] = packed[i0 + i]; sa.subs[i] = static_cast<char*>(scratch) + (size_t)(i0 + i) * sub_bytes; }
+    if (int rc = strm::launch_sub(sa, MI_F16, pattern, (hipStream_t)stream)) return rc;
   }
-  // 2. the rolling metering over the group (its own workspace: the last of the n + 1)
-  const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
-  float* ws_meter = static_cast<float*>(ws) + (size_t)n * ws_floats;
-  if (int rc = mi_isp_metering(subs, n, Hs, Ws, 1, MI_F16, state9, alpha, ws_meter, stream)) return rc;
-  // 3. the cameras through one resident launch
+  return 0;
+}
+
+// step 3: the cameras through one resident launch, with the Reinhard scalars of state9 (read on the device)
+extern "C" int mi_isp_camera_group_tonemap(const uint8_t* const* packed, void* const* images, uint8_t* const* outs, int n, int H,
+                                           int W, int pattern, const float* ccm9, const float* state9, float gamma,
+                                           float intensity, float light_adapt, float color_adapt, void* ws, void* stream) {
+  const char* who = "camera_group_tonemap";
+  MI_REQUIRE(outs && state9 && ws, "%s: null pointer", who);
+  MI_REQUIRE(gamma > 0.f, "%s: gamma must be positive", who);
+  hipStream_t s = (hipStream_t)stream;
+  tile::Params p = {};
+  if (int rc = camera_group_params(p, packed, images, outs, n, H, W, pattern, ccm9, who)) return rc;
+  strm::SArgs ma = {};
+  MI_REQUIRE(camera_group_fits(H, W, pattern, ma),
+             "%s: the frame does not fit the resident grid (mi_isp_camera_group_fits); use mi_isp_camera_frame_batch", who);
+  p.out_dtype = MI_U8; p.out_scale = 255.f; p.gamma_inv = 1.0f / gamma; p.la = light_adapt; p.ca = color_adapt;
   p.part_stride = mi_partial_cap(H, W);
   ma.t = p;
   ma.n_px = (float)((int64_t)H * W); ma.intensity = intensity; ma.fp_w = nullptr; ma.bounds_post = 0;
+  const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
   int dev = 0;
   MI_HIP(hipGetDevice(&dev));
   MI_REQUIRE(dev >= 0 && dev < 16, "%s: device index %d out of range", who, dev);
@@ -887,6 +897,33 @@ extern "C" int mi_isp_camera_group_reinhard(const uint8_t* const* packed, void* 
   if (int rc = mega::launch_cam(cb, pattern, s)) return rc;
   if (direct) { if (int rc = ew::resident_leave_locked(dev, s)) return rc; }
   return 0;
+}
+
+extern "C" int mi_isp_camera_group_reinhard(const uint8_t* const* packed, void* const* images, uint8_t* const* outs, int n,
+                                            int H, int W, int pattern, const float* ccm9, float* state9, float alpha,
+                                            float gamma, float intensity, float light_adapt, float color_adapt,
+                                            void* scratch, void* ws, void* stream) {
+  const char* who = "camera_group_reinhard";
+  MI_REQUIRE(packed && outs && state9 && scratch && ws, "%s: null pointer", who);
+  MI_REQUIRE(n >= 1 && n <= mega::MAX_BATCH, "%s: 1 .. %d cameras per call", who, mega::MAX_BATCH);
+  {                                                          // refuse before anything is launched
+    strm::SArgs ma = {};
+    MI_REQUIRE(camera_group_fits(H, W, pattern, ma),
+               "%s: the frame does not fit the resident grid (mi_isp_camera_group_fits); use mi_isp_camera_frame_batch", who);
+  }
+  // 1. the subsample of every camera, straight from its packed frame
+  if (int rc = mi_isp_camera_group_subsample(packed, n, H, W, pattern, ccm9, scratch, stream)) return rc;
+  // 2. the rolling metering over the group (its own workspace: the last of the n + 1)
+  const int Hs = (H + 7) / 8, Ws = (W + 7) / 8;
+  const size_t sub_bytes = mi_isp_camera_group_scratch_bytes(1, H, W);
+  const void* subs[mega::MAX_BATCH];
+  for (int i = 0; i < n; ++i) subs[i] = static_cast<char*>(scratch) + (size_t)i * sub_bytes;
+  const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
+  float* ws_meter = static_cast<float*>(ws) + (size_t)n * ws_floats;
+  if (int rc = mi_isp_metering(subs, n, Hs, Ws, 1, MI_F16, state9, alpha, ws_meter, stream)) return rc;
+  // 3. the cameras through one resident launch
+  return mi_isp_camera_group_tonemap(packed, images, outs, n, H, W, pattern, ccm9, state9, gamma, intensity, light_adapt,
+                                     color_adapt, ws, stream);
 }
 
 // ---- a batch as a HIP graph: capture once, replay per step ---------------------------------------------------------

@@ -43,6 +43,19 @@ def _run_isp(frames_of_step, group, dev):
     return metrics, outs
 
 
+def _run_group(frames_of_step, group, dev):
+    """The same three steps at full resolution through ISP.process_packed12 (the camera-group kernel; sharded: subsample ->
+    metering with its two all-gathers -> the persistent launch)."""
+    import taichi_image_amd as ti
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev, process_group=group)
+    metrics, outs = [], []
+    for step in range(STEPS):
+        o = isp.process_packed12([torch.from_numpy(p).to(dev) for p in frames_of_step(step)], gamma=0.6)
+        metrics.append(isp.metrics.cpu().numpy().copy())
+        outs.append([x.cpu().numpy() for x in o])
+    return metrics, outs
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -56,7 +69,9 @@ def _worker(rank, world, port, q):
     metrics, outs = _run_isp(mine, dist.group.WORLD, dev)
     # config 4: this rank's share of independent frames through the stateless chain
     stateless = [pipeline12_reinhard(torch.from_numpy(p).to(dev), whole_frame=False).cpu().numpy() for p in mine(0)]   # two processes share this GPU: not the whole-frame kernel
-    q.put((rank, metrics, outs, stateless))
+    # (the frames are small: the resident grids of the two processes fit the chip side by side)
+    gm, go = _run_group(mine, dist.group.WORLD, dev)
+    q.put((rank, metrics, outs, stateless, gm, go))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,8 +87,8 @@ def test_two_ranks_through_the_hip_kernels():
         p.start()
     got = {}
     for _ in range(world):
-        rank, metrics, outs, stateless = q.get(timeout=240)
-        got[rank] = (metrics, outs, stateless)
+        rank, metrics, outs, stateless, gm, go = q.get(timeout=240)
+        got[rank] = (metrics, outs, stateless, gm, go)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -90,6 +105,16 @@ def test_two_ranks_through_the_hip_kernels():
                 d = np.abs(o.astype(np.int32) - want.astype(np.int32))
                 assert d.max() <= 1 and (d > 0).mean() < 0.01, (step, r, j, d.max())
         assert np.array_equal(got[0][0][step], got[1][0][step])     # identical state on every rank
+    # ISP.process_packed12 on a sharded group against the same call on one rank holding all six cameras
+    gmetrics, gouts = _run_group(lambda step: [_packed(step, k) for k in range(6)], None, dev)
+    for step in range(STEPS):
+        for r in range(world):
+            m = got[r][3][step]
+            assert np.allclose(m, gmetrics[step], rtol=3e-6, atol=1e-7), (step, r, m, gmetrics[step])
+            for j, o in enumerate(got[r][4][step]):
+                d = np.abs(o.astype(np.int32) - gouts[step][r + world * j].astype(np.int32))
+                assert d.max() <= 1 and (d > 0).mean() < 0.01, ("process_packed12", step, r, j, d.max())
+        assert np.array_equal(got[0][3][step], got[1][3][step])
     full = [pipeline12_reinhard(torch.from_numpy(_packed(0, k)).to(dev), whole_frame=False).cpu().numpy() for k in range(6)]
     for r in range(world):
         for j, o in enumerate(got[r][2]):
