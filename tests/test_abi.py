@@ -71,6 +71,19 @@ def test_argument_validation_reports_errors():
     assert L.mi_isp_load_packed_metered_is_fused(3072, 4096, 12, 0, 2, 4) == 0 and L.mi_isp_load_packed_metered_is_fused(70, 204, 12, 0, 2, 8) == 0
     assert L.mi_isp_load_packed_metered_is_fused(3072, 4096, 16, 0, 2, 8) == 0 and L.mi_isp_load_packed_metered_is_fused(3072, 4096, 12, 1, 2, 8) == 0
     assert L.mi_isp_whole_frame_set_poll_limit(0) == 0
+    # the camera-group entry points (round 4) validate before they touch a device too
+    f = ctypes.c_float
+    assert L.mi_isp_camera_group_reinhard(None, None, None, 1, 64, 512, 0, None, None, f(0), f(1), f(1), f(1), f(0), None, None, None) != 0
+    assert b"null" in L.mi_isp_last_error()
+    assert L.mi_isp_camera_group_reinhard(one, None, one, 0, 64, 512, 0, None, p, f(0), f(1), f(1), f(1), f(0), p, p, None) != 0
+    assert b"cameras per call" in L.mi_isp_last_error()
+    assert L.mi_isp_camera_group_subsample(one, 65, 64, 512, 0, None, p, None) != 0
+    assert L.mi_isp_camera_group_tonemap(one, None, one, 1, 64, 512, 0, None, p, f(0), f(1), f(1), f(0), p, None) != 0      # gamma 0
+    assert b"gamma" in L.mi_isp_last_error()
+    assert L.mi_isp_camera_group_scratch_bytes(6, 3072, 4096) == 6 * 384 * 512 * 3 * 2
+    assert L.mi_isp_camera_group_scratch_bytes(1, 70, 204) == (9 * 26 * 3 * 2 + 255) // 256 * 256 and L.mi_isp_camera_group_scratch_bytes(0, 8, 8) == 0
+    assert L.mi_isp_camera_group_fits(3072, 4096, 0, 3, 8) == 0 and L.mi_isp_camera_group_fits(3072, 4096, 0, 2, 4) == 0      # f32 / stride 4: no
+    assert L.mi_isp_camera_group_set_poll_limit(0) == 0
 
 
 def test_no_cpu_fallback():
