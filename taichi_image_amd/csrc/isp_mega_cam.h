@@ -18,6 +18,11 @@
 // HBM sees the packed frame in (18.9 MB at 4K) and the u8 image out (37.7 MB), plus 75.5 MB when p is kept - against
 // 358 MB of the load -> metering -> pass 1 -> pass 2 sequence.  The arithmetic is that of strm::stream_kernel<S_STORE> and
 // rgb_pass_kernel<PM_ISP_RH_P1 / P2> instruction for instruction (same helpers): tests/ compare the two paths bit for bit.
+//
+// The skeleton of the frame loop (geometry, first loads, phase A) is frame_kernel's, REPEATED here rather than shared: that
+// body sits at exactly 256 VGPRs without a spill, and factoring its lambdas out moves its register allocation (every edit
+// of isp_mega.h in rounds 3 and 4 was checked against the kernel's assembly).  The barrier, the posts, the reductions and the
+// row helpers are shared (isp_mega.h, isp_stream.h).
 #pragma once
 #include "isp_mega.h"
 
