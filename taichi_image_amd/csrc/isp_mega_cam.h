@@ -44,6 +44,35 @@ struct CBatch {
   CamIO io[MAX_BATCH];
 };
 
+// 12 floats -> 12 u8, packed into three dwords: cast_out<uint8_t> (clamp to [0, 255], truncate, NaN -> 0) in ONE
+// instruction per value.  v_cvt_pk_u8_f32 converts, saturates and drops the byte into its place in a dword; it rounds by
+// the MODE register's single-precision rounding mode, so the conversions sit between two s_setreg (round toward zero, back
+// to nearest-even) inside one asm block that nothing else can be scheduled into.  scratch/cvt_pk_u8_test.hip: equal to
+// clamp + truncation for fractions, ties, out-of-range values, infinities and NaN.  Against v_med3 + v_cvt_u32 + the
+// byte packing (v_perm / v_or3) it saves ~2 instructions per value: phase D is issue-bound when gamma != 1.
+MI_DEV void pack12_u8_rtz(const float* v, uint32_t (&d)[3]) {
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "s_nop 1\n\t"
+      "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+      "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+      "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
+      "s_nop 1"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]),
+        "v"(v[11]));
+}
+
 template <int PR, int PC>
 __global__ __launch_bounds__(THREADS, 2) void camera_kernel(const CBatch cb) {
   typedef half_t E;
@@ -214,23 +243,35 @@ __global__ __launch_bounds__(THREADS, 2) void camera_kernel(const CBatch cb) {
   // The operands of the phase are set up at its start, every frame (frame_kernel: no registers to park them in).
   ReinhardK rk;
   const bool ca0 = p.ca == 0.f;
-  const float lo = vgpr(sh_fp[FP_LO]), inv = vgpr(sh_fp[FP_INV]);
+  const float inv = vgpr(sh_fp[FP_INV]);
   rk.la = vgpr(p.la); rk.ca = vgpr(p.ca);
   rk.map_key = vgpr(sh_fp[FP_MAPKEY]); rk.ei = vgpr(sh_fp[FP_EI]);
   rk.mean3[0] = vgpr(sh_fp[FP_MEAN3]); rk.mean3[1] = vgpr(sh_fp[FP_MEAN3 + 1]); rk.mean3[2] = vgpr(sh_fp[FP_MEAN3 + 2]);
   float vmax = -__builtin_inff();
-  auto tone_row = [&](auto ca0_c, const float (&t)[24], float (&q)[24]) {
+  // isp_norm (camera_isp.py:200: no clamp) of element e of a packed row: the difference straight from the half
+  // (v_fma_mix_f32: h * 1 + (-lo), the half widened exactly, one rounding - the bits of converting first and subtracting),
+  // then the product, rounded where it is made (isp_math.h: isp_norm)
+  const float nlo = vgpr(-sh_fp[FP_LO]);
+  auto norm_pk = [&](auto ec, const uint32_t (&pk)[12]) __attribute__((always_inline)) {
+    constexpr int e = decltype(ec)::value;
+    float d;
+    if constexpr ((e & 1) == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pk[e / 2]), "v"(nlo));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pk[e / 2]), "v"(nlo));
+    return f32_rounded(d * inv);
+  };
+  auto tone_row = [&](auto ca0_c, const uint32_t (&pk)[12], float (&q)[24]) {
     constexpr bool CA0 = decltype(ca0_c)::value;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    static_for<0, 8>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
       float x[3], o[3];
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) x[ch] = isp_norm(t[3 * k + ch], lo, inv);      // camera_isp.py:200: no clamp here
+      x[0] = norm_pk(std::integral_constant<int, 3 * k>{}, pk);
+      x[1] = norm_pk(std::integral_constant<int, 3 * k + 1>{}, pk);
+      x[2] = norm_pk(std::integral_constant<int, 3 * k + 2>{}, pk);
       reinhard_px<CA0>(x, rk, o);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) q[3 * k + ch] = o[ch];
       vmax = fmaxf(vmax, fmaxf(o[0], fmaxf(o[1], o[2])));
-    }
+    });
   };
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
@@ -238,10 +279,9 @@ __global__ __launch_bounds__(THREADS, 2) void camera_kernel(const CBatch cb) {
     if (r_begin + RR < r_end) {
       uint32_t pk[12];
       resident_pk(rrc, pk);
-      float t[24], q[24];
-      unpack_row(pk, t);
-      if (ca0) tone_row(std::true_type{}, t, q);
-      else tone_row(std::false_type{}, t, q);
+      float q[24];
+      if (ca0) tone_row(std::true_type{}, pk, q);
+      else tone_row(std::false_type{}, pk, q);
       // p as the reference stores it over its image (camera_isp.py:211: ti.cast(p, f16)), in the pixel's place
 #pragma unroll
       for (int j = 0; j < 12; ++j) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk[j]) : "v"(f32_rounded(q[2 * j])), "v"(f32_rounded(q[2 * j + 1])));
@@ -285,9 +325,9 @@ __global__ __launch_bounds__(THREADS, 2) void camera_kernel(const CBatch cb) {
     uint32_t pk[12];
     resident_pk(rrc, pk);
     float o[24];
-    unpack_row(pk, o);
-#pragma unroll
-    for (int j = 0; j < 24; ++j) o[j] = o[j] * maxout_inv;
+    // p / max_out straight from the packed halves (v_fma_mix_f32 with a zero addend: the half is widened exactly, the product
+    // rounded once - the bits of converting first and multiplying, one instruction instead of two)
+    static_for<0, 24>([&](auto ec) { constexpr int e = decltype(ec)::value; o[e] = mul_mix_h<e>(pk[e / 2], maxout_inv); });
     if (gamma_inv != 1.f) {
       asm volatile("" ::: "memory");                    // (a real branch: see linear_n)
 #pragma unroll
@@ -303,7 +343,11 @@ __global__ __launch_bounds__(THREADS, 2) void camera_kernel(const CBatch cb) {
       __builtin_memcpy(mine, pk, sizeof(mine));
       wave_store_units<uint4, 3, ST_KEEP>(prsrc, row * (uint32_t)p.W * 6u + (uint32_t)bx * BAND * 6u, off16, lane, stage, mine);
     }
-    wave_store_row_t<uint8_t, ST_STREAM>(orsrc, row * (uint32_t)p.W * 3u + (uint32_t)bx * BAND * 3u, off8, lane, stage, o);
+    uint32_t d0[3], d1[3];
+    pack12_u8_rtz(o, d0);
+    pack12_u8_rtz(o + 12, d1);
+    const uint2 mine8[3] = {make_uint2(d0[0], d0[1]), make_uint2(d0[2], d1[0]), make_uint2(d1[1], d1[2])};
+    wave_store_units<uint2, 3, ST_STREAM>(orsrc, row * (uint32_t)p.W * 3u + (uint32_t)bx * BAND * 3u, off8, lane, stage, mine8);
   };
   static_for<0, ROWS>([&](auto rrc) {
     constexpr int RR = decltype(rrc)::value;
