@@ -389,6 +389,9 @@ def camera_isp(name: str, dtype=types.f32):
                 if L.mi_isp_reinhard_faults(1):
                     raise TonemapTimeout("an earlier tonemap_reinhard on this device timed out waiting for an image's "
                                          "max_out: the outputs of that call are invalid")
+                if L.mi_isp_camera_group_faults(1):
+                    raise TonemapTimeout("an earlier process_packed12 on this device timed out waiting for an image's "
+                                         "max_out: the outputs of that call are invalid")
             if self.process_group is None:
                 metering = prev.clone()
                 _native.check(L.mi_isp_metering(ptrs, len(images), H, W, stride, dtype.code,
