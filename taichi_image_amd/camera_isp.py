@@ -513,6 +513,8 @@ def camera_isp(name: str, dtype=types.f32):
                      and all(isinstance(f, torch.Tensor) and f.ndim == 2 and f.dtype == torch.uint8 and f.shape == f0.shape
                              for f in frames)
                      and f0.shape[1] % 3 == 0)
+            if fused and torch.cuda.is_current_stream_capturing():
+                fused = False                  # (a captured resident launch can be neither ordered against others nor checked)
             if fused:
                 h, w = f0.shape[0], f0.shape[1] * 2 // 3
                 with torch.cuda.device(self.device):
