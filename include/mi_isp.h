@@ -112,6 +112,11 @@ int mi_isp_transform(const void* src_dev, void* dst_dev, int Hs, int Ws, int dty
  * in the environment selects the four-launch path (bounds pass, finalize, statistics pass, finalize). */
 int mi_isp_metering(const void* const* images_host, int n_images, int H, int W, int stride,
                     int dtype, float* state9_dev, float alpha, void* ws_dev, void* stream);
+/* The same with the previous state only READ and the new one only WRITTEN (camera_isp.py:172-173 clones the previous
+ * state and lets the kernel update the clone; this form needs no copy).  prev9_dev == state9_dev is mi_isp_metering.
+ * After a barrier timeout state9_dev holds the previous state. */
+int mi_isp_metering_to(const void* const* images_host, int n_images, int H, int W, int stride, int dtype,
+                       const float* prev9_dev, float* state9_dev, float alpha, void* ws_dev, void* stream);
 /* The two data passes of the same kernel, split so that a cross-GPU reduction can be
  * inserted between them (one process per GPU, see taichi_image_amd/distributed.py):
  *  bounds: raw (min, max) of the subsample                          -> out2_dev  (f32[2])
@@ -243,7 +248,8 @@ int mi_isp_camera_frame_batch(const uint8_t* const* packed_host, void* const* im
  *   packed_host / outs_host: host arrays of n device pointers (12-bit standard layout; u8 (H, W, 3), 8-byte aligned).
  *   images_host: NULL (the bench's case: p is not stored anywhere), or n device pointers to (H, W, 3) f16 buffers
  *     (16-byte aligned) that receive what the reference leaves in its loaded images: p, camera_isp.py:211.
- *   state9_dev / alpha: as mi_isp_camera_frame_batch.  Metering stride 8, f16 work dtype (Camera16), 1 <= n <= 64.
+ *   prev9_dev -> state9_dev, alpha: the metering state before and after this group (mi_isp_metering_to; the two may be the
+ *     same buffer), alpha as mi_isp_camera_frame_batch.  Metering stride 8, f16 work dtype (Camera16), 1 <= n <= 64.
  *   scratch_dev: mi_isp_camera_group_scratch_bytes(n, H, W) bytes (the subsamples).
  *   ws_dev: (n + 1) x mi_isp_workspace_bytes(H, W) bytes, zero-filled once (a workspace per camera + the metering's).
  * mi_isp_camera_group_fits: 1 if the frame fits the resident grid (as mi_isp_pipeline12_whole_frame_fits) with this
@@ -253,9 +259,9 @@ int mi_isp_camera_frame_batch(const uint8_t* const* packed_host, void* const* im
  * that call are invalid.  mi_isp_camera_group_set_poll_limit(polls): poll budget of later launches (0 = default; tests: 1).
  * Launched in the one order of the library's resident-grid kernels (see mi_isp_whole_frame_set_sabotage). */
 int mi_isp_camera_group_reinhard(const uint8_t* const* packed_host, void* const* images_host, uint8_t* const* outs_host,
-                                 int n, int H, int W, int pattern, const float* ccm9_host, float* state9_dev, float alpha,
-                                 float gamma, float intensity, float light_adapt, float color_adapt, void* scratch_dev,
-                                 void* ws_dev, void* stream);
+                                 int n, int H, int W, int pattern, const float* ccm9_host, const float* prev9_dev,
+                                 float* state9_dev, float alpha, float gamma, float intensity, float light_adapt,
+                                 float color_adapt, void* scratch_dev, void* ws_dev, void* stream);
 /* The same in its steps, for callers that put something between them (taichi_image_amd: the sharded metering of a
  * multi-GPU group, two all-gathers between the subsample and the tone map):
  *   mi_isp_camera_group_subsample: image[::8, ::8] of every camera's (never materialised) image - (ceil(H / 8), ceil(W / 8), 3)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mi_isp_resize_bilinear": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P]),
     "mi_isp_transform": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "mi_isp_metering": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P]),
+    "mi_isp_metering_to": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P]),
     "mi_isp_metering_bounds": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "mi_isp_metering_sums": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "mi_isp_reinhard": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_float, c_float, c_float, c_float, c_int, _P, _P]),
@@ -71,7 +72,7 @@ SIGNATURES = {
                                           POINTER(c_float), c_int, c_int, c_int, c_float, c_int, _P, c_float, c_int, c_float,
                                           c_float, c_float, c_float, c_int, _P, _P]),
     "mi_isp_camera_group_reinhard": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, POINTER(c_float),
-                                             _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P]),
+                                             _P, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P]),
     "mi_isp_camera_group_subsample": (c_int, [POINTER(_P), c_int, c_int, c_int, c_int, POINTER(c_float), _P, _P]),
     "mi_isp_camera_group_tonemap": (c_int, [POINTER(_P), POINTER(_P), POINTER(_P), c_int, c_int, c_int, c_int, POINTER(c_float),
                                             _P, c_float, c_float, c_float, c_float, _P, _P]),

@@ -393,9 +393,11 @@ def camera_isp(name: str, dtype=types.f32):
                     raise TonemapTimeout("an earlier process_packed12 on this device timed out waiting for an image's "
                                          "max_out: the outputs of that call are invalid")
             if self.process_group is None:
-                metering = prev.clone()
-                _native.check(L.mi_isp_metering(ptrs, len(images), H, W, stride, dtype.code,
-                                                metering.data_ptr(), float(t), ws.data_ptr(), stream))
+                # (the reference clones `prev` and lets the kernel update the clone, camera_isp.py:172-173; here the kernel
+                # reads `prev` and writes the new tensor: no copy kernel - 4 us - in front of every update)
+                metering = torch.empty_like(prev)
+                _native.check(L.mi_isp_metering_to(ptrs, len(images), H, W, stride, dtype.code, prev.data_ptr(),
+                                                   metering.data_ptr(), float(t), ws.data_ptr(), stream))
                 return metering
             # sharded batch: the same two data passes, an all-gather after each (two collectives per call), the ranks'
             # rows combined by one small kernel each on this stream (mi_isp_metering_combine_*)
@@ -535,9 +537,10 @@ def camera_isp(name: str, dtype=types.f32):
             outputs = [torch.empty((h, w, 3), dtype=torch.uint8, device=self.device) for _ in srcs]
             images = [torch.empty((h, w, 3), dtype=torch_dtype, device=self.device) for _ in srcs] if keep_images else None
             if self.metrics is None:                         # camera_isp.py:376-385
-                metrics, t = torch.zeros(9, dtype=torch.float32, device=self.device), 0.0
+                prev, t = torch.zeros(9, dtype=torch.float32, device=self.device), 0.0
             else:
-                metrics, t = self.metrics.clone(), 1.0 - self.moving_alpha
+                prev, t = self.metrics, 1.0 - self.moving_alpha
+            metrics = torch.empty_like(prev)                 # (the previous state is read, the new one written: no clone)
             scratch = torch.empty(int(L.mi_isp_camera_group_scratch_bytes(n, h, w)), dtype=torch.uint8, device=self.device)
             ws = _native.workspace(h, w, self.device, slots=n + 1)
             stream = _native.stream_ptr(self.device)
@@ -545,7 +548,7 @@ def camera_isp(name: str, dtype=types.f32):
             ccm = _native.ccm_arg(self.color_correct_matrix)
             if self.process_group is None:
                 _native.check(L.mi_isp_camera_group_reinhard(
-                    p_srcs, p_imgs, p_outs, n, h, w, self._demosaic_pattern.value, ccm, metrics.data_ptr(), float(t),
+                    p_srcs, p_imgs, p_outs, n, h, w, self._demosaic_pattern.value, ccm, prev.data_ptr(), metrics.data_ptr(), float(t),
                     float(gamma), float(intensity), float(light_adapt), float(color_adapt), scratch.data_ptr(), ws.data_ptr(),
                     stream))
                 self.metrics = metrics
@@ -556,7 +559,7 @@ def camera_isp(name: str, dtype=types.f32):
             per = int(L.mi_isp_camera_group_scratch_bytes(1, h, w))
             hs, ws_ = (h + 7) // 8, (w + 7) // 8
             subs = [scratch[i * per:i * per + hs * ws_ * 6].view(torch_dtype).view(hs, ws_, 3) for i in range(n)]
-            self.metrics = self._metering_images(subs, t, metrics, stride=1)
+            self.metrics = self._metering_images(subs, t, prev, stride=1)
             _native.check(L.mi_isp_camera_group_tonemap(
                 p_srcs, p_imgs, p_outs, n, h, w, self._demosaic_pattern.value, ccm, self.metrics.data_ptr(), float(gamma),
                 float(intensity), float(light_adapt), float(color_adapt), ws.data_ptr(), stream))

@@ -725,6 +725,8 @@ extern "C" int mi_isp_pipeline12_reinhard_batch(const uint8_t* const* packed, vo
 // orientation transform folded into the u8 store: what a frame group costs a C caller is this one call on its stream.
 extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
                                float alpha, void* ws, void* stream);
+extern "C" int mi_isp_metering_to(const void* const* images, int n_images, int H, int W, int stride, int dtype,
+                                  const float* prev9, float* state9, float alpha, void* ws, void* stream);
 extern "C" int mi_isp_reinhard_batch(void* const* images, uint8_t* const* outs, int n, int H, int W, int dtype,
                                      const float* state9, float gamma, float intensity, float light_adapt,
                                      float color_adapt, int transform, void* ws, void* stream);
@@ -900,11 +902,11 @@ extern "C" int mi_isp_camera_group_tonemap(const uint8_t* const* packed, void* c
 }
 
 extern "C" int mi_isp_camera_group_reinhard(const uint8_t* const* packed, void* const* images, uint8_t* const* outs, int n,
-                                            int H, int W, int pattern, const float* ccm9, float* state9, float alpha,
-                                            float gamma, float intensity, float light_adapt, float color_adapt,
+                                            int H, int W, int pattern, const float* ccm9, const float* prev9, float* state9,
+                                            float alpha, float gamma, float intensity, float light_adapt, float color_adapt,
                                             void* scratch, void* ws, void* stream) {
   const char* who = "camera_group_reinhard";
-  MI_REQUIRE(packed && outs && state9 && scratch && ws, "%s: null pointer", who);
+  MI_REQUIRE(packed && outs && prev9 && state9 && scratch && ws, "%s: null pointer", who);
   MI_REQUIRE(n >= 1 && n <= mega::MAX_BATCH, "%s: 1 .. %d cameras per call", who, mega::MAX_BATCH);
   {                                                          // refuse before anything is launched
     strm::SArgs ma = {};
@@ -920,7 +922,7 @@ extern "C" int mi_isp_camera_group_reinhard(const uint8_t* const* packed, void* 
   for (int i = 0; i < n; ++i) subs[i] = static_cast<char*>(scratch) + (size_t)i * sub_bytes;
   const size_t ws_floats = mi_isp_workspace_bytes(H, W) / sizeof(float);
   float* ws_meter = static_cast<float*>(ws) + (size_t)n * ws_floats;
-  if (int rc = mi_isp_metering(subs, n, Hs, Ws, 1, MI_F16, state9, alpha, ws_meter, stream)) return rc;
+  if (int rc = mi_isp_metering_to(subs, n, Hs, Ws, 1, MI_F16, prev9, state9, alpha, ws_meter, stream)) return rc;
   // 3. the cameras through one resident launch
   return mi_isp_camera_group_tonemap(packed, images, outs, n, H, W, pattern, ccm9, state9, gamma, intensity, light_adapt,
                                      color_adapt, ws, stream);

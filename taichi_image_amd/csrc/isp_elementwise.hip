@@ -1227,7 +1227,8 @@ struct MeterFused {
   float* fp;                 // FrameParams of the workspace (FP_LO / FP_HI are left as the multi-launch path leaves them)
   float* rec0;               // n_blocks records of 16 bytes: {min, max, -, tag}
   float* rec1;               // n_blocks records of 48 bytes: {gmin, gmax, slog2, tag} {sgray, s0, s1, tag} {s2, -, -, tag}
-  float* state9;
+  float* state9;             // receives the new state ...
+  const float* prev9;        // ... blended with this one (may be state9 itself: in place)
   float alpha, n_px;
   uint32_t tag;              // phase 0; phase 1 = tag + 1
   unsigned spin_limit;
@@ -1322,8 +1323,8 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
     lo = wave_min(lo); hi = wave_max(hi);
     if (lane == 0) {
       // camera_isp.py:156-157: b = lerp(alpha, new, prev) = new + alpha * (prev - new)  (ew::FIN_ISP_BOUNDS)
-      sh_b[0] = lo + a.alpha * (a.state9[0] - lo);
-      sh_b[1] = hi + a.alpha * (a.state9[1] - hi);
+      sh_b[0] = lo + a.alpha * (a.prev9[0] - lo);
+      sh_b[1] = hi + a.alpha * (a.prev9[1] - hi);
       if (block == 0) { a.fp[FP_LO] = sh_b[0]; a.fp[FP_HI] = sh_b[1]; }
     }
   }
@@ -1417,6 +1418,7 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
         __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.mailbox) __hip_atomic_store(a.mailbox, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      if (a.state9 != a.prev9 && lane < 9) a.state9[lane] = a.prev9[lane];     // "unchanged" for a state that is written elsewhere
       return;
     }
     float gmin = __builtin_inff(), gmax = -__builtin_inff();
@@ -1436,7 +1438,7 @@ __global__ __launch_bounds__(METER_THREADS) void metering_fused_kernel(const Met
     if (lane == 0) {
       tot[0] = gmin; tot[1] = gmax;
       ew::FinArgs fa = {};
-      fa.fp = a.fp; fa.state9 = a.state9; fa.bounds_in = sh_b; fa.n_px = a.n_px; fa.alpha = a.alpha;
+      fa.fp = a.fp; fa.state9 = a.state9; fa.state9_in = a.prev9; fa.bounds_in = sh_b; fa.n_px = a.n_px; fa.alpha = a.alpha;
       ew::finalize_scalars(ew::FIN_ISP_STATS, fa, tot);
     }
     MI_METER_STAMP(5);
@@ -1978,8 +1980,8 @@ extern "C" int mi_isp_metering_combine_sums(const float* gathered, int n_ranks, 
 static std::atomic<uint32_t> g_meter_launches{0};
 // Its launches take part in the one order of the library's resident grids (ew::resident_order, isp_elementwise.h).
 static std::atomic<unsigned> g_meter_poll_limit{0};          // 0 = default; tests: mi_isp_metering_set_poll_limit
-static int metering_fused(const void* const* images, int n_images, int H, int W, int stride, int dtype, float* state9,
-                          float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done) {
+static int metering_fused(const void* const* images, int n_images, int H, int W, int stride, int dtype, const float* prev9,
+                          float* state9, float alpha, float* fp, float* partials, int cap, hipStream_t s, bool* done) {
   *done = false;
   const char* env = getenv("MI_ISP_METERING_LAUNCHES");       // (read per call: a test switches it)
   if ((env && atoi(env) == 4) || n_images > 64 || n_images > METER_MAX_BLOCKS) return 0;
@@ -2000,7 +2002,7 @@ static int metering_fused(const void* const* images, int n_images, int H, int W,
   for (int i = 0; i < 64; ++i) a.imgs.p[i] = i < n_images ? images[i] : nullptr;
   a.H = H; a.W = W; a.stride = stride; a.bpi = bpi; a.n_images = n_images;
   a.fp = fp; a.rec0 = partials; a.rec1 = partials + cap;       // partial rows 0 and 1..3 (cap >= 1024 floats each)
-  a.state9 = state9; a.alpha = alpha; a.n_px = (float)((int64_t)n_images * hs * wss);
+  a.state9 = state9; a.prev9 = prev9; a.alpha = alpha; a.n_px = (float)((int64_t)n_images * hs * wss);
   // a quiet NaN with a payload, two per launch (0x7FC00001 ...): see the kernel's head
   const uint32_t k = g_meter_launches.fetch_add(1, std::memory_order_relaxed);
   a.tag = 0x7FC00001u + 2u * (k % 0x1FFFFFu);
@@ -2075,29 +2077,36 @@ int resident_leave_locked(int dev, hipStream_t s) {
 }
 }  // namespace ew
 
-extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype,
-                               float* state9, float alpha, void* ws, void* stream) {
+// prev9 -> state9 (camera_isp.py:172-173: `metering = prev.clone()`, then the kernel updates the clone - here without the
+// copy: the previous state is only read, the new one only written; prev9 == state9 is the in-place form)
+extern "C" int mi_isp_metering_to(const void* const* images, int n_images, int H, int W, int stride, int dtype,
+                                  const float* prev9, float* state9, float alpha, void* ws, void* stream) {
   if (int rc = metering_check(images, n_images, H, W, stride, dtype, ws)) return rc;
-  MI_REQUIRE(state9, "metering: null state");
+  MI_REQUIRE(state9 && prev9, "metering: null state");
   hipStream_t s = (hipStream_t)stream;
   float* fp = static_cast<float*>(ws);
   float* partials = fp + FP_COUNT;
   const int cap = mi_partial_cap(H, W);
   {
     bool done = false;
-    if (int rc = metering_fused(images, n_images, H, W, stride, dtype, state9, alpha, fp, partials, cap, s, &done)) return rc;
+    if (int rc = metering_fused(images, n_images, H, W, stride, dtype, prev9, state9, alpha, fp, partials, cap, s, &done)) return rc;
     if (done) return 0;
   }
   int nb = 0;
   if (int rc = metering_pass(0, images, n_images, H, W, stride, dtype, nullptr, partials, cap, &nb, s)) return rc;
   FinArgs fa = {};
-  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp; fa.state9 = state9; fa.alpha = alpha;
+  fa.partials = partials; fa.stride = cap; fa.nblocks = nb; fa.fp = fp; fa.state9 = state9; fa.state9_in = prev9; fa.alpha = alpha;
   if (int rc = finalize(FIN_ISP_BOUNDS, fa, s)) return rc;
   if (int rc = metering_pass(1, images, n_images, H, W, stride, dtype, fp + FP_LO, partials, cap, &nb, s)) return rc;
   const int hs = (H + stride - 1) / stride, wss = (W + stride - 1) / stride;
   fa.nblocks = nb;
   fa.n_px = (float)((int64_t)n_images * hs * wss);
   return finalize(FIN_ISP_STATS, fa, s);
+}
+
+extern "C" int mi_isp_metering(const void* const* images, int n_images, int H, int W, int stride, int dtype,
+                               float* state9, float alpha, void* ws, void* stream) {
+  return mi_isp_metering_to(images, n_images, H, W, stride, dtype, state9, state9, alpha, ws, stream);
 }
 
 // ---- ISP tonemaps ----------------------------------------------------------------------------

@@ -21,6 +21,7 @@ struct FinArgs {
   const float* partials; int stride; int nblocks;
   float* fp;            // FrameParams
   float* state9;        // ISP state (in/out) or NULL
+  const float* state9_in;  // the previous state when it is not to be overwritten (NULL: state9 itself, in place)
   const float* bounds_in;  // FIN_ISP_SUMS/FIN_ISP_STATS: blended bounds (device) or NULL -> fp
   float* out;           // raw outputs (FIN_ISP_SUMS, FIN_RAW_BOUNDS)
   float n_px;           // pixel count for the means
@@ -68,7 +69,8 @@ MI_DEV void finalize_scalars(int mode, const FinArgs& a, const double* tot) {
       break;
     case FIN_ISP_BOUNDS: {
       // camera_isp.py:156-157: b = lerp(alpha, new, prev) = new + alpha * (prev - new)
-      const float pmin = a.state9[0], pmax = a.state9[1];
+      const float* prev = a.state9_in ? a.state9_in : a.state9;
+      const float pmin = prev[0], pmax = prev[1];
       fp[FP_LO] = lo + a.alpha * (pmin - lo);
       fp[FP_HI] = hi + a.alpha * (pmax - hi);
       break;
@@ -91,7 +93,8 @@ MI_DEV void finalize_scalars(int mode, const FinArgs& a, const double* tot) {
         const float n = a.n_px;
         const float* b = a.bounds_in ? a.bounds_in : fp + FP_LO;
         const float v[9] = {b[0], b[1], lmin, lmax, slog / n, sgray / n, s0 / n, s1 / n, s2 / n};
-        for (int i = 0; i < 9; ++i) a.state9[i] = v[i] + a.alpha * (a.state9[i] - v[i]);
+        const float* prev = a.state9_in ? a.state9_in : a.state9;
+        for (int i = 0; i < 9; ++i) a.state9[i] = v[i] + a.alpha * (prev[i] - v[i]);
       } else {
         // tonemap.py:99-103 (log_bounds = (lmin, -lmax): reference sign quirk), :115-119
         const float n = a.n_px;

@@ -73,9 +73,9 @@ def test_argument_validation_reports_errors():
     assert L.mi_isp_whole_frame_set_poll_limit(0) == 0
     # the camera-group entry points (round 4) validate before they touch a device too
     f = ctypes.c_float
-    assert L.mi_isp_camera_group_reinhard(None, None, None, 1, 64, 512, 0, None, None, f(0), f(1), f(1), f(1), f(0), None, None, None) != 0
+    assert L.mi_isp_camera_group_reinhard(None, None, None, 1, 64, 512, 0, None, None, None, f(0), f(1), f(1), f(1), f(0), None, None, None) != 0
     assert b"null" in L.mi_isp_last_error()
-    assert L.mi_isp_camera_group_reinhard(one, None, one, 0, 64, 512, 0, None, p, f(0), f(1), f(1), f(1), f(0), p, p, None) != 0
+    assert L.mi_isp_camera_group_reinhard(one, None, one, 0, 64, 512, 0, None, p, p, f(0), f(1), f(1), f(1), f(0), p, p, None) != 0
     assert b"cameras per call" in L.mi_isp_last_error()
     assert L.mi_isp_camera_group_subsample(one, 65, 64, 512, 0, None, p, None) != 0
     assert L.mi_isp_camera_group_tonemap(one, None, one, 1, 64, 512, 0, None, p, f(0), f(1), f(1), f(0), p, None) != 0      # gamma 0

@@ -487,7 +487,7 @@ def test_camera_group_reinhard_through_the_c_abi_full_size(ti, dev, scenes):
         want = isp.tonemap_reinhard(want_imgs, gamma=0.6, intensity=1.2, light_adapt=0.8, color_adapt=0.0)
         alpha = 0.0 if group == 0 else 1.0 - 0.25
         rc = L.mi_isp_camera_group_reinhard(_native.ptr_array(packs), _native.ptr_array(images) if group == 1 else None,
-                                            _native.ptr_array(outs), n, H, W, 0, None, state.data_ptr(), ctypes.c_float(alpha),
+                                            _native.ptr_array(outs), n, H, W, 0, None, state.data_ptr(), state.data_ptr(), ctypes.c_float(alpha),
                                             ctypes.c_float(0.6), ctypes.c_float(1.2), ctypes.c_float(0.8), ctypes.c_float(0.0),
                                             scratch.data_ptr(), ws.data_ptr(), _native.stream_ptr(dev))
         assert rc == 0, L.mi_isp_last_error()

@@ -941,6 +941,26 @@ def test_isp_process_packed12_equals_the_two_calls(ti, dev, shape, n, pattern, k
                 assert torch.equal(images[k].view(torch.int16), want_images[k].view(torch.int16)), f"group {group} camera {k}: p"
 
 
+def test_isp_metrics_are_rebound_not_overwritten(ti, dev):
+    """camera_isp.py:172-173,376-385: every update leaves `isp.metrics` bound to a NEW tensor and the previous one as it was
+    (the reference clones it first).  Round 4 dropped the clone - the kernel reads the old state and writes the new tensor -
+    so the property is tested: through tonemap_reinhard, update_metering and process_packed12."""
+    H, W = 96, 512
+    fr = [[torch.from_numpy(natural_packed12(np.random.default_rng(1400 + 10 * s + k), H, W, dark=0.05 * s)).to(dev) for k in range(2)]
+          for s in range(4)]
+    isp = ti.Camera16(ti.BayerPattern.RGGB, moving_alpha=0.3, device=dev)
+    isp.tonemap_reinhard([isp.load_packed12(f) for f in fr[0]], gamma=0.6)
+    for step, call in enumerate((lambda f: isp.tonemap_reinhard([isp.load_packed12(x) for x in f], gamma=0.6),
+                                 lambda f: isp.update_metering([isp.load_packed12(x) for x in f]),
+                                 lambda f: isp.process_packed12(f, gamma=0.6)), start=1):
+        old, snap = isp.metrics, isp.metrics.clone()
+        call(fr[step])
+        torch.cuda.synchronize()
+        assert isp.metrics is not old and isp.metrics.data_ptr() != old.data_ptr(), step
+        assert torch.equal(old, snap), f"call {step} wrote into the previous metrics tensor"
+        assert not torch.equal(isp.metrics, snap), step
+
+
 def test_isp_process_packed12_against_the_oracle(ti, dev):
     """The same call against the oracle's load -> update_metering -> reinhard_isp (camera_isp.py:333-340,376-385,177-218)."""
     from oracle import c_oracle
