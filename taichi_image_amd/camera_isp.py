@@ -487,11 +487,12 @@ def camera_isp(name: str, dtype=types.f32):
             return outputs
 
         def process_packed12(self, frames: List[torch.Tensor], gamma: float = 1.0, intensity: float = 1.0,
-                             light_adapt: float = 1.0, color_adapt: float = 0.0, keep_images: bool = False):
+                             light_adapt: float = 1.0, color_adapt: float = 0.0, keep_images: bool = False,
+                             ids_format: bool = False):
             """Extension (not in the reference): one step of the reference's own bench in one call -
             `Processor.__call__` of bench/camera_isp.py:23-27:
 
-                images = [isp.load_packed12(f) for f in frames]
+                images = [isp.load_packed12(f, ids_format) for f in frames]
                 return isp.tonemap_reinhard(images, gamma=...)
 
             with the same u8 outputs and the same metering state afterwards, bit for bit.  For a full-resolution
@@ -509,7 +510,7 @@ def camera_isp(name: str, dtype=types.f32):
             assert len(frames) > 0, "need at least one frame"
             L = _native.lib()
             f0 = frames[0]
-            fused = (dtype is types.f16 and self.resize_width == 0 and self.scale is None
+            fused = (dtype is types.f16 and not ids_format and self.resize_width == 0 and self.scale is None
                      and self.transform == interpolate.ImageTransform.none and self.metering_stride == 8
                      and 1 <= len(frames) <= 64
                      and all(isinstance(f, torch.Tensor) and f.ndim == 2 and f.dtype == torch.uint8 and f.shape == f0.shape
@@ -522,7 +523,7 @@ def camera_isp(name: str, dtype=types.f32):
                 with torch.cuda.device(self.device):
                     fused = bool(L.mi_isp_camera_group_fits(h, w, self._demosaic_pattern.value, dtype.code, 8))
             if not fused:
-                images = self.load_packed12_batch(frames)
+                images = self.load_packed12_batch(frames, ids_format)
                 outputs = self.tonemap_reinhard(images, gamma, intensity, light_adapt, color_adapt)
                 return (outputs, images) if keep_images else outputs
             srcs = [f.to(self.device).contiguous() for f in frames]

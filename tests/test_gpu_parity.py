@@ -985,11 +985,12 @@ def test_isp_process_packed12_falls_back_to_the_two_calls(ti, dev):
     H, W, n = 64, 512, 2
     frames = [torch.from_numpy(natural_packed12(np.random.default_rng(1200 + k), H, W, dark=0.03 * k)).to(dev) for k in range(n)]
     for cam, extra in (("Camera32", {}), ("Camera16", dict(resize_width=256)), ("Camera16", dict(transform=ti.ImageTransform.rotate_90)),
-                       ("Camera16", dict(metering_stride=4))):
+                       ("Camera16", dict(metering_stride=4)), ("Camera16", dict(ids=True))):
+        ids = extra.pop("ids", False)                     # the IDS byte layout (packed.py:37-44): a call argument
         a = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, **extra)
         b = getattr(ti, cam)(ti.BayerPattern.RGGB, device=dev, **extra)
-        outs, images = a.process_packed12(frames, gamma=0.6, keep_images=True)
-        want_images = [b.load_packed12(f) for f in frames]
+        outs, images = a.process_packed12(frames, gamma=0.6, keep_images=True, ids_format=ids)
+        want_images = [b.load_packed12(f, ids) for f in frames]
         want = b.tonemap_reinhard(want_images, gamma=0.6)
         assert torch.equal(a.metrics, b.metrics), (cam, extra)
         for k in range(n):
